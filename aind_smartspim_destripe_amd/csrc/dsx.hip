@@ -1,0 +1,693 @@
+// dsx.hip -- C ABI of the MI355X destripe engine (see include/dsx.h) and the launch pipeline.
+//
+// Pipeline per cohort of <= max_batch planes (one HIP stream, no host synchronisation inside):
+//   memset(control)  ->  k_dwt_fwd x L  ->  k_hist x L  ->  k_otsu  ->  k_rowfilter x L
+//   ->  k_idwt x (L-1)  ->  k_idwt<final>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dsx.h"
+#include "dsx_kernels.h"
+#include "dsx_plan.h"
+
+namespace {
+
+thread_local std::string g_init_error;
+
+enum KernelClass { KC_FWD1 = 0, KC_FWD, KC_HIST, KC_OTSU, KC_ROW, KC_INV, KC_FINAL, KC_COUNT };
+const char* kClassNames[KC_COUNT] = {"k_dwt_fwd(level1)", "k_dwt_fwd(coarse)", "k_hist", "k_otsu",
+                                     "k_rowfilter",       "k_idwt(pyramid)",   "k_idwt(final)"};
+
+struct ProfRec {
+  int cls;
+  hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct dsx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool planned = false;
+  dsx::Plan plan;
+  dsx::HostCfg cfg[2];
+  double high_int = 2700.0;
+  int max_batch = 0;
+  // sigmoid(float16((x - 400) / 20)) > 0.3 of filtering.py:78-80  <=>  float16(x) >= 383.25  <=>
+  // x > 383.125 (round-to-nearest-even), checked against every float16 pattern in tests/golden
+  float fg_cutoff = 383.12503f;
+  // device buffers
+  float* d_ws = nullptr;          // [max_batch][plane_floats]
+  char* d_ctl = nullptr;          // control block, zeroed per cohort (stats | minmax | hist)
+  size_t ctl_zero_bytes = 0;
+  dsx::PlaneStats* d_stats = nullptr;
+  unsigned* d_minmax = nullptr;
+  unsigned* d_hist = nullptr;
+  float* d_thr = nullptr;
+  float* d_otsu = nullptr;
+  int* d_cfg = nullptr;
+  double* d_means = nullptr;
+  dsx::C32* d_consts = nullptr;
+  size_t consts_bytes = 0;
+  float* d_flat = nullptr;
+  float* d_dark = nullptr;
+  bool own_shading = false;
+  int dark_h = 0, dark_w = 0;
+  // staging for dsx_run_host
+  void* d_stage_in = nullptr;
+  void* d_stage_out = nullptr;
+  size_t stage_in_bytes = 0, stage_out_bytes = 0;
+  // last cohort (debug hooks)
+  int last_n = 0;
+  int stop_after = 0;
+  // timing
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool profiling = false;
+  std::vector<ProfRec> prof;
+  size_t workspace_bytes = 0;
+};
+
+namespace {
+
+int fail(dsx_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define DSX_HIP(call)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(ctx, DSX_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+void free_plan_buffers(dsx_ctx* c) {
+  auto fr = [](void* p) { if (p) (void)hipFree(p); };
+  fr(c->d_ws); c->d_ws = nullptr;
+  fr(c->d_ctl); c->d_ctl = nullptr;
+  fr(c->d_thr); c->d_thr = nullptr;
+  fr(c->d_otsu); c->d_otsu = nullptr;
+  fr(c->d_cfg); c->d_cfg = nullptr;
+  fr(c->d_means); c->d_means = nullptr;
+  fr(c->d_consts); c->d_consts = nullptr;
+  if (c->own_shading) { fr(c->d_flat); fr(c->d_dark); }
+  c->d_flat = c->d_dark = nullptr;
+  c->own_shading = false;
+  fr(c->d_stage_in); c->d_stage_in = nullptr; c->stage_in_bytes = 0;
+  fr(c->d_stage_out); c->d_stage_out = nullptr; c->stage_out_bytes = 0;
+  c->planned = false;
+}
+
+struct LaunchScope {
+  dsx_ctx* c;
+  bool on;
+  ProfRec r;
+  LaunchScope(dsx_ctx* c_, int cls) : c(c_), on(c_->profiling) {
+    if (on) {
+      r.cls = cls;
+      (void)hipEventCreate(&r.e0);
+      (void)hipEventCreate(&r.e1);
+      (void)hipEventRecord(r.e0, c->stream);
+    }
+  }
+  ~LaunchScope() {
+    if (on) {
+      (void)hipEventRecord(r.e1, c->stream);
+      c->prof.push_back(r);
+    }
+  }
+};
+
+template <int CPL>
+hipError_t launch_rowfilter(const dsx::RowArgs& a, dim3 grid, size_t smem, hipStream_t s) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)dsx::k_rowfilter<CPL>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev & 63] = true;
+  }
+  hipLaunchKernelGGL(dsx::k_rowfilter<CPL>, grid, dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
+hipError_t dispatch_rowfilter(const dsx::RowArgs& a, dim3 grid, hipStream_t s) {
+  const size_t smem = (size_t)a.M * 5 * sizeof(float2);
+  const int cpl = (a.M + 63) / 64;
+  if (cpl <= 2) return launch_rowfilter<2>(a, grid, smem, s);
+  if (cpl <= 4) return launch_rowfilter<4>(a, grid, smem, s);
+  if (cpl <= 6) return launch_rowfilter<6>(a, grid, smem, s);
+  if (cpl <= 10) return launch_rowfilter<10>(a, grid, smem, s);
+  if (cpl <= 18) return launch_rowfilter<18>(a, grid, smem, s);
+  return launch_rowfilter<36>(a, grid, smem, s);
+}
+
+// One cohort of nb planes through the whole chain (asynchronous).
+int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out, int out_dtype,
+               int32_t* d_cfg_used) {
+  const dsx::Plan& p = ctx->plan;
+  hipStream_t s = ctx->stream;
+  const int L = p.L;
+  DSX_HIP(hipMemsetAsync(ctx->d_ctl, 0, ctx->ctl_zero_bytes, s));
+
+  // ---- forward transform ------------------------------------------------------------------
+  for (int l = 0; l < L; ++l) {
+    const dsx::LevelPlan& lp = p.lv[l];
+    dsx::FwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = d_in;
+    a.in_plane_stride = (long long)p.H * p.W;
+    a.ws = ctx->d_ws;
+    a.ws_plane_stride = p.plane_floats;
+    a.in_off = (l > 0) ? p.lv[l - 1].aa_off : 0;
+    a.hin = lp.hin; a.win = lp.win; a.ldin = lp.ldin;
+    a.aa_off = lp.aa_off; a.da_off = lp.da_off;
+    a.h = lp.h; a.w = lp.w; a.ld = lp.ld;
+    a.minmax = ctx->d_minmax;
+    a.lvl = l; a.L = L;
+    a.stats = ctx->d_stats;
+    a.fg_cutoff = ctx->fg_cutoff;
+    dim3 grid((lp.w + dsx::kFwdTW - 1) / dsx::kFwdTW, (lp.h + dsx::kFwdTH - 1) / dsx::kFwdTH, nb);
+    LaunchScope ls(ctx, l == 0 ? KC_FWD1 : KC_FWD);
+    if (l > 0) {
+      hipLaunchKernelGGL(dsx::k_dwt_fwd<2>, grid, dim3(256), 0, s, a);
+    } else if (in_dtype == DSX_U16) {
+      hipLaunchKernelGGL(dsx::k_dwt_fwd<0>, grid, dim3(256), 0, s, a);
+    } else {
+      hipLaunchKernelGGL(dsx::k_dwt_fwd<1>, grid, dim3(256), 0, s, a);
+    }
+    DSX_HIP(hipGetLastError());
+  }
+  if (L == 0) {
+    // no level runs: the statistic is not needed (both configs are the identity + 2)
+  }
+
+  // ---- thresholds -----------------------------------------------------------------------------
+  for (int l = 0; l < L; ++l) {
+    const dsx::LevelPlan& lp = p.lv[l];
+    dsx::HistArgs a;
+    a.ws = ctx->d_ws;
+    a.ws_plane_stride = p.plane_floats;
+    a.da_off = lp.da_off;
+    a.h = lp.h; a.w = lp.w; a.ld = lp.ld;
+    a.minmax = ctx->d_minmax;
+    a.hist = ctx->d_hist;
+    a.lvl = l; a.L = L;
+    a.rows_per_block = 32;
+    dim3 grid((lp.h + a.rows_per_block - 1) / a.rows_per_block, nb);
+    LaunchScope ls(ctx, KC_HIST);
+    hipLaunchKernelGGL(dsx::k_hist, grid, dim3(256), 0, s, a);
+    DSX_HIP(hipGetLastError());
+  }
+  if (L > 0) {
+    dsx::OtsuArgs a;
+    a.stats = ctx->d_stats;
+    a.npix = (double)p.H * (double)p.W;
+    a.high_int = ctx->high_int;
+    a.minmax = ctx->d_minmax;
+    a.hist = ctx->d_hist;
+    a.thr = ctx->d_thr;
+    a.otsu = ctx->d_otsu;
+    a.cfg = ctx->d_cfg;
+    a.means = ctx->d_means;
+    a.max_thr[0] = (float)ctx->cfg[0].max_threshold;
+    a.max_thr[1] = (float)ctx->cfg[1].max_threshold;
+    a.L = L;
+    LaunchScope ls(ctx, KC_OTSU);
+    hipLaunchKernelGGL(dsx::k_otsu, dim3(L, nb), dim3(64), 0, s, a);
+    DSX_HIP(hipGetLastError());
+    if (d_cfg_used)
+      DSX_HIP(hipMemcpyAsync(d_cfg_used, ctx->d_cfg, sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, s));
+  } else if (d_cfg_used) {
+    DSX_HIP(hipMemsetAsync(d_cfg_used, 0, sizeof(int32_t) * nb, s));
+  }
+  if (ctx->stop_after == 1) return DSX_OK;
+
+  // ---- row filter -----------------------------------------------------------------------------
+  for (int l = 0; l < L; ++l) {
+    const dsx::LevelPlan& lp = p.lv[l];
+    dsx::RowArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ws = ctx->d_ws;
+    a.ws_plane_stride = p.plane_floats;
+    a.da_off = lp.da_off;
+    a.h = lp.h; a.w = lp.w; a.ld = lp.ld;
+    a.thr = ctx->d_thr;
+    a.cfg = ctx->d_cfg;
+    a.lvl = l; a.L = L;
+    a.lvl_active[0] = p.cfg_levels[0];
+    a.lvl_active[1] = p.cfg_levels[1];
+    a.M = lp.M; a.K = lp.K;
+    a.npass = lp.npass;
+    for (int i = 0; i < lp.npass; ++i) a.radix[i] = lp.radix[i];
+    a.tw = (const float2*)(ctx->d_consts + lp.tw_off);
+    a.g[0] = (const float2*)(ctx->d_consts + lp.g_off[0]);
+    a.g[1] = (const float2*)(ctx->d_consts + lp.g_off[1]);
+    a.inv_M = 1.0f / (float)lp.M;
+    const int npairs = (lp.h + 1) / 2;
+    dim3 grid((npairs + 3) / 4, nb);
+    LaunchScope ls(ctx, KC_ROW);
+    DSX_HIP(dispatch_rowfilter(a, grid, s));
+  }
+  if (ctx->stop_after == 2) return DSX_OK;
+
+  // ---- inverse transform of the Delta pyramid + finish ---------------------------------------
+  for (int l = L - 1; l >= 0; --l) {
+    const dsx::LevelPlan& lp = p.lv[l];
+    dsx::InvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ws = ctx->d_ws;
+    a.ws_plane_stride = p.plane_floats;
+    a.c_off = lp.aa_off;
+    a.d_off = lp.da_off;
+    a.hc = lp.h; a.wc = lp.w; a.ldc = lp.ld;
+    a.has_c = (l < L - 1) ? 1 : 0;
+    a.has_pyr = 1;
+    if (l > 0) {
+      const dsx::LevelPlan& lo = p.lv[l - 1];
+      a.out_off = lo.aa_off;
+      a.hout = lo.h; a.wout = lo.w; a.ldout = lo.ld;
+      dim3 grid((a.wout + dsx::kInvTW - 1) / dsx::kInvTW, (a.hout + dsx::kInvTH - 1) / dsx::kInvTH, nb);
+      LaunchScope ls(ctx, KC_INV);
+      hipLaunchKernelGGL(dsx::k_idwt<0>, grid, dim3(256), 0, s, a);
+      DSX_HIP(hipGetLastError());
+    } else {
+      a.hout = p.Hout; a.wout = p.Wout; a.ldout = p.Wout;
+      a.img = d_in;
+      a.img_plane_stride = (long long)p.H * p.W;
+      a.H = p.H; a.W = p.W;
+      a.out = d_out;
+      a.out_plane_stride = (long long)p.Hout * p.Wout;
+      a.out_dtype = (out_dtype == DSX_U16) ? 0 : 1;
+      a.flat = ctx->d_flat;
+      a.dark = ctx->d_dark;
+      a.dark_ld = ctx->dark_w;
+      dim3 grid((a.wout + dsx::kInvTW - 1) / dsx::kInvTW, (a.hout + dsx::kInvTH - 1) / dsx::kInvTH, nb);
+      LaunchScope ls(ctx, KC_FINAL);
+      if (in_dtype == DSX_U16) {
+        hipLaunchKernelGGL(dsx::k_idwt<1>, grid, dim3(256), 0, s, a);
+      } else {
+        hipLaunchKernelGGL(dsx::k_idwt<2>, grid, dim3(256), 0, s, a);
+      }
+      DSX_HIP(hipGetLastError());
+    }
+  }
+  if (L == 0) {
+    dsx::InvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ws = ctx->d_ws;
+    a.ws_plane_stride = p.plane_floats;
+    a.has_pyr = 0;
+    a.hout = p.Hout; a.wout = p.Wout; a.ldout = p.Wout;
+    a.img = d_in;
+    a.img_plane_stride = (long long)p.H * p.W;
+    a.H = p.H; a.W = p.W;
+    a.out = d_out;
+    a.out_plane_stride = (long long)p.Hout * p.Wout;
+    a.out_dtype = (out_dtype == DSX_U16) ? 0 : 1;
+    a.flat = ctx->d_flat;
+    a.dark = ctx->d_dark;
+    a.dark_ld = ctx->dark_w;
+    dim3 grid((a.wout + dsx::kInvTW - 1) / dsx::kInvTW, (a.hout + dsx::kInvTH - 1) / dsx::kInvTH, nb);
+    LaunchScope ls(ctx, KC_FINAL);
+    if (in_dtype == DSX_U16) {
+      hipLaunchKernelGGL(dsx::k_idwt<1>, grid, dim3(256), 0, s, a);
+    } else {
+      hipLaunchKernelGGL(dsx::k_idwt<2>, grid, dim3(256), 0, s, a);
+    }
+    DSX_HIP(hipGetLastError());
+  }
+  return DSX_OK;
+}
+
+size_t elem_size(int dtype) { return dtype == DSX_U16 ? 2 : 4; }
+
+}  // namespace
+
+extern "C" {
+
+int dsx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* dsx_last_error(const dsx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int dsx_init(int device, dsx_ctx** out_ctx) {
+  if (!out_ctx) { g_init_error = "out_ctx is NULL"; return DSX_EINVAL; }
+  *out_ctx = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_init_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+    return DSX_EHIP;
+  }
+  if (device < 0 || device >= n) { g_init_error = "device index out of range"; return DSX_EINVAL; }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) { g_init_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return DSX_EHIP; }
+  dsx_ctx* c = new dsx_ctx();
+  c->device = device;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&c->t0);
+  if (e == hipSuccess) e = hipEventCreate(&c->t1);
+  if (e != hipSuccess) {
+    g_init_error = std::string("stream/event creation: ") + hipGetErrorString(e);
+    delete c;
+    return DSX_EHIP;
+  }
+  *out_ctx = c;
+  return DSX_OK;
+}
+
+void dsx_destroy(dsx_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  free_plan_buffers(ctx);
+  if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+  if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int dsx_plan(dsx_ctx* ctx, int height, int width, int max_batch, const dsx_cfg* cells_config,
+             const dsx_cfg* no_cells_config, double microscope_high_int, const float* flat,
+             const float* dark, int dark_h, int dark_w) {
+  if (!ctx) return DSX_EINVAL;
+  if (!cells_config || !no_cells_config) return fail(ctx, DSX_EINVAL, "config is NULL");
+  if (max_batch < 1) return fail(ctx, DSX_EINVAL, "max_batch must be >= 1");
+  if ((flat == nullptr) != (dark == nullptr))
+    return fail(ctx, DSX_EINVAL, "flatfield and darkfield must be given together");
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  free_plan_buffers(ctx);
+
+  const dsx_cfg* src[2] = {no_cells_config, cells_config};  // index 1 == cells_config
+  for (int c = 0; c < 2; ++c) {
+    if (src[c]->wavelet != DSX_WAVELET_DB3) return fail(ctx, DSX_EINVAL, "only wavelet db3 is implemented");
+    ctx->cfg[c].level = src[c]->level;
+    ctx->cfg[c].sigma = src[c]->sigma;
+    ctx->cfg[c].max_threshold = src[c]->max_threshold;
+  }
+  const std::string perr = dsx::build_plan(height, width, ctx->cfg, ctx->plan);
+  if (!perr.empty()) {
+    const bool limit = perr.find("too") != std::string::npos;
+    return fail(ctx, limit ? DSX_ELIMIT : DSX_EINVAL, perr);
+  }
+  const dsx::Plan& p = ctx->plan;
+  ctx->high_int = microscope_high_int;
+  ctx->max_batch = max_batch;
+  const int L = p.L, Lc = L > 0 ? L : 1;
+
+  const size_t ws_bytes = (size_t)max_batch * p.plane_floats * sizeof(float);
+  DSX_HIP(hipMalloc((void**)&ctx->d_ws, ws_bytes));
+  const size_t stats_b = sizeof(dsx::PlaneStats) * max_batch;
+  const size_t minmax_b = sizeof(unsigned) * 2 * Lc * max_batch;
+  const size_t hist_b = sizeof(unsigned) * 256 * Lc * max_batch;
+  ctx->ctl_zero_bytes = stats_b + minmax_b + hist_b;
+  DSX_HIP(hipMalloc((void**)&ctx->d_ctl, ctx->ctl_zero_bytes));
+  ctx->d_stats = (dsx::PlaneStats*)ctx->d_ctl;
+  ctx->d_minmax = (unsigned*)(ctx->d_ctl + stats_b);
+  ctx->d_hist = (unsigned*)(ctx->d_ctl + stats_b + minmax_b);
+  DSX_HIP(hipMalloc((void**)&ctx->d_thr, sizeof(float) * Lc * max_batch));
+  DSX_HIP(hipMalloc((void**)&ctx->d_otsu, sizeof(float) * Lc * max_batch));
+  DSX_HIP(hipMalloc((void**)&ctx->d_cfg, sizeof(int) * max_batch));
+  DSX_HIP(hipMalloc((void**)&ctx->d_means, sizeof(double) * 2 * max_batch));
+  DSX_HIP(hipMemset(ctx->d_cfg, 0, sizeof(int) * max_batch));
+  DSX_HIP(hipMemset(ctx->d_means, 0, sizeof(double) * 2 * max_batch));
+  DSX_HIP(hipMemset(ctx->d_thr, 0, sizeof(float) * Lc * max_batch));
+  DSX_HIP(hipMemset(ctx->d_otsu, 0, sizeof(float) * Lc * max_batch));
+  ctx->consts_bytes = std::max<size_t>(p.consts.size(), 1) * sizeof(dsx::C32);
+  DSX_HIP(hipMalloc((void**)&ctx->d_consts, ctx->consts_bytes));
+  if (!p.consts.empty())
+    DSX_HIP(hipMemcpy(ctx->d_consts, p.consts.data(), p.consts.size() * sizeof(dsx::C32), hipMemcpyHostToDevice));
+  ctx->workspace_bytes = ws_bytes + ctx->ctl_zero_bytes + ctx->consts_bytes;
+
+  if (flat) {
+    if (dark_h < p.Hout || dark_w < p.Wout)
+      return fail(ctx, DSX_EINVAL, "Please, check the shape of the darkfield.");
+    const size_t fb = sizeof(float) * (size_t)p.Hout * p.Wout;
+    const size_t db = sizeof(float) * (size_t)dark_h * dark_w;
+    DSX_HIP(hipMalloc((void**)&ctx->d_flat, fb));
+    DSX_HIP(hipMalloc((void**)&ctx->d_dark, db));
+    ctx->own_shading = true;
+    DSX_HIP(hipMemcpy(ctx->d_flat, flat, fb, hipMemcpyHostToDevice));
+    DSX_HIP(hipMemcpy(ctx->d_dark, dark, db, hipMemcpyHostToDevice));
+    ctx->dark_h = dark_h;
+    ctx->dark_w = dark_w;
+    ctx->workspace_bytes += fb + db;
+  }
+  ctx->planned = true;
+  ctx->last_n = 0;
+  return DSX_OK;
+}
+
+int dsx_set_shading_device(dsx_ctx* ctx, const float* d_flat, const float* d_dark, int dark_h,
+                           int dark_w) {
+  if (!ctx) return DSX_EINVAL;
+  if (!ctx->planned) return fail(ctx, DSX_ENOPLAN, "dsx_plan has not been called");
+  if ((d_flat == nullptr) != (d_dark == nullptr))
+    return fail(ctx, DSX_EINVAL, "flatfield and darkfield must be given together");
+  if (d_flat && (dark_h < ctx->plan.Hout || dark_w < ctx->plan.Wout))
+    return fail(ctx, DSX_EINVAL, "Please, check the shape of the darkfield.");
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->own_shading) { (void)hipFree(ctx->d_flat); (void)hipFree(ctx->d_dark); }
+  ctx->own_shading = false;
+  ctx->d_flat = const_cast<float*>(d_flat);
+  ctx->d_dark = const_cast<float*>(d_dark);
+  ctx->dark_h = dark_h;
+  ctx->dark_w = dark_w;
+  return DSX_OK;
+}
+
+int dsx_constants_device(const dsx_ctx* ctx, void** d_ptr, size_t* bytes) {
+  if (!ctx || !ctx->planned || !d_ptr || !bytes) return DSX_EINVAL;
+  *d_ptr = ctx->d_consts;
+  *bytes = ctx->plan.consts.size() * sizeof(dsx::C32);
+  return DSX_OK;
+}
+
+int dsx_plan_info(const dsx_ctx* ctx, dsx_plan_info_t* info) {
+  if (!ctx || !info) return DSX_EINVAL;
+  if (!ctx->planned) return DSX_ENOPLAN;
+  memset(info, 0, sizeof(*info));
+  const dsx::Plan& p = ctx->plan;
+  info->height = p.H; info->width = p.W;
+  info->out_height = p.Hout; info->out_width = p.Wout;
+  info->levels = p.L;
+  for (int l = 0; l < p.L && l < 16; ++l) {
+    info->level_h[l] = p.lv[l].h;
+    info->level_w[l] = p.lv[l].w;
+    info->fft_len[l] = p.lv[l].M;
+    info->fft_halo[l] = p.lv[l].K;
+  }
+  info->max_batch = ctx->max_batch;
+  info->workspace_bytes = ctx->workspace_bytes;
+  return DSX_OK;
+}
+
+int dsx_run_device(dsx_ctx* ctx, const void* d_in, int in_dtype, int n, void* d_out, int out_dtype,
+                   int32_t* d_cfg_used) {
+  if (!ctx) return DSX_EINVAL;
+  if (!ctx->planned) return fail(ctx, DSX_ENOPLAN, "dsx_plan has not been called");
+  if (n < 0 || (n > 0 && (!d_in || !d_out))) return fail(ctx, DSX_EINVAL, "bad plane pointers / count");
+  if ((in_dtype != DSX_U16 && in_dtype != DSX_F32) || (out_dtype != DSX_U16 && out_dtype != DSX_F32))
+    return fail(ctx, DSX_EINVAL, "unknown element type");
+  DSX_HIP(hipSetDevice(ctx->device));
+  const dsx::Plan& p = ctx->plan;
+  const size_t in_plane = (size_t)p.H * p.W * elem_size(in_dtype);
+  const size_t out_plane = (size_t)p.Hout * p.Wout * elem_size(out_dtype);
+  for (int start = 0; start < n; start += ctx->max_batch) {
+    const int nb = std::min(ctx->max_batch, n - start);
+    const int rc = run_cohort(ctx, (const char*)d_in + start * in_plane, in_dtype, nb,
+                              (char*)d_out + start * out_plane, out_dtype,
+                              d_cfg_used ? d_cfg_used + start : nullptr);
+    if (rc != DSX_OK) return rc;
+    ctx->last_n = nb;
+  }
+  return DSX_OK;
+}
+
+int dsx_sync(dsx_ctx* ctx) {
+  if (!ctx) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  return DSX_OK;
+}
+
+int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, int out_dtype,
+                 int32_t* cfg_used) {
+  if (!ctx) return DSX_EINVAL;
+  if (!ctx->planned) return fail(ctx, DSX_ENOPLAN, "dsx_plan has not been called");
+  if (n < 0 || (n > 0 && (!in || !out))) return fail(ctx, DSX_EINVAL, "bad plane pointers / count");
+  if ((in_dtype != DSX_U16 && in_dtype != DSX_F32) || (out_dtype != DSX_U16 && out_dtype != DSX_F32))
+    return fail(ctx, DSX_EINVAL, "unknown element type");
+  DSX_HIP(hipSetDevice(ctx->device));
+  const dsx::Plan& p = ctx->plan;
+  const size_t in_plane = (size_t)p.H * p.W * elem_size(in_dtype);
+  const size_t out_plane = (size_t)p.Hout * p.Wout * elem_size(out_dtype);
+  const int B = ctx->max_batch;
+  const size_t need_in = in_plane * B, need_out = out_plane * B + sizeof(int32_t) * B;
+  if (ctx->stage_in_bytes < need_in) {
+    if (ctx->d_stage_in) (void)hipFree(ctx->d_stage_in);
+    ctx->d_stage_in = nullptr; ctx->stage_in_bytes = 0;
+    DSX_HIP(hipMalloc(&ctx->d_stage_in, need_in));
+    ctx->stage_in_bytes = need_in;
+  }
+  if (ctx->stage_out_bytes < need_out) {
+    if (ctx->d_stage_out) (void)hipFree(ctx->d_stage_out);
+    ctx->d_stage_out = nullptr; ctx->stage_out_bytes = 0;
+    DSX_HIP(hipMalloc(&ctx->d_stage_out, need_out));
+    ctx->stage_out_bytes = need_out;
+  }
+  int32_t* d_cfg = (int32_t*)((char*)ctx->d_stage_out + out_plane * B);
+  for (int start = 0; start < n; start += B) {
+    const int nb = std::min(B, n - start);
+    DSX_HIP(hipMemcpyAsync(ctx->d_stage_in, (const char*)in + start * in_plane, in_plane * nb,
+                           hipMemcpyHostToDevice, ctx->stream));
+    const int rc = run_cohort(ctx, ctx->d_stage_in, in_dtype, nb, ctx->d_stage_out, out_dtype, d_cfg);
+    if (rc != DSX_OK) return rc;
+    ctx->last_n = nb;
+    if (ctx->stop_after == 0)
+      DSX_HIP(hipMemcpyAsync((char*)out + start * out_plane, ctx->d_stage_out, out_plane * nb,
+                             hipMemcpyDeviceToHost, ctx->stream));
+    if (cfg_used)
+      DSX_HIP(hipMemcpyAsync(cfg_used + start, d_cfg, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
+    DSX_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return DSX_OK;
+}
+
+/* ---- memory + timing helpers ------------------------------------------------------------------ */
+int dsx_malloc(dsx_ctx* ctx, size_t bytes, void** d_ptr) {
+  if (!ctx || !d_ptr) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+  if (e != hipSuccess) return fail(ctx, DSX_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return DSX_OK;
+}
+int dsx_free(dsx_ctx* ctx, void* d_ptr) {
+  if (!ctx) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipFree(d_ptr));
+  return DSX_OK;
+}
+int dsx_memcpy_h2d(dsx_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+  if (!ctx) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  return DSX_OK;
+}
+int dsx_memcpy_d2h(dsx_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+  if (!ctx) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  return DSX_OK;
+}
+int dsx_memcpy_d2d(dsx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+  if (!ctx) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return DSX_OK;
+}
+int dsx_timer_start(dsx_ctx* ctx) {
+  if (!ctx) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipEventRecord(ctx->t0, ctx->stream));
+  return DSX_OK;
+}
+int dsx_timer_stop(dsx_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipEventRecord(ctx->t1, ctx->stream));
+  DSX_HIP(hipEventSynchronize(ctx->t1));
+  DSX_HIP(hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+  return DSX_OK;
+}
+int dsx_profile_enable(dsx_ctx* ctx, int on) {
+  if (!ctx) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  ctx->prof.clear();
+  ctx->profiling = on != 0;
+  return DSX_OK;
+}
+int dsx_profile_read(dsx_ctx* ctx, int max_classes, float* ms, int32_t* launches, const char** names,
+                     int* n_classes) {
+  if (!ctx || !ms || !launches || !n_classes) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  const int nc = std::min<int>(max_classes, KC_COUNT);
+  for (int i = 0; i < nc; ++i) { ms[i] = 0.f; launches[i] = 0; if (names) names[i] = kClassNames[i]; }
+  for (auto& r : ctx->prof) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess && r.cls < nc) { ms[r.cls] += t; launches[r.cls]++; }
+  }
+  *n_classes = nc;
+  return DSX_OK;
+}
+
+/* ---- debug hooks ---------------------------------------------------------------------------- */
+int dsx_set_stop_after(dsx_ctx* ctx, int stage) {
+  if (!ctx || stage < 0 || stage > 2) return DSX_EINVAL;
+  ctx->stop_after = stage;
+  return DSX_OK;
+}
+int dsx_get_stats(dsx_ctx* ctx, int plane, double* fore_mean, double* back_mean, int32_t* cfg_used) {
+  if (!ctx) return DSX_EINVAL;
+  if (!ctx->planned) return fail(ctx, DSX_ENOPLAN, "dsx_plan has not been called");
+  if (plane < 0 || plane >= ctx->last_n) return fail(ctx, DSX_EINVAL, "plane index outside the last cohort");
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  double m[2];
+  int c = 0;
+  DSX_HIP(hipMemcpy(m, ctx->d_means + 2 * plane, sizeof(m), hipMemcpyDeviceToHost));
+  DSX_HIP(hipMemcpy(&c, ctx->d_cfg + plane, sizeof(int), hipMemcpyDeviceToHost));
+  if (fore_mean) *fore_mean = m[0];
+  if (back_mean) *back_mean = m[1];
+  if (cfg_used) *cfg_used = c;
+  return DSX_OK;
+}
+int dsx_get_thresholds(dsx_ctx* ctx, int plane, int level, float* otsu, float* threshold) {
+  if (!ctx) return DSX_EINVAL;
+  if (!ctx->planned) return fail(ctx, DSX_ENOPLAN, "dsx_plan has not been called");
+  if (plane < 0 || plane >= ctx->last_n || level < 0 || level >= ctx->plan.L)
+    return fail(ctx, DSX_EINVAL, "plane / level index out of range");
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  const size_t i = (size_t)plane * ctx->plan.L + level;
+  if (otsu) DSX_HIP(hipMemcpy(otsu, ctx->d_otsu + i, sizeof(float), hipMemcpyDeviceToHost));
+  if (threshold) DSX_HIP(hipMemcpy(threshold, ctx->d_thr + i, sizeof(float), hipMemcpyDeviceToHost));
+  return DSX_OK;
+}
+int dsx_get_level(dsx_ctx* ctx, int plane, int level, int stage, float* out) {
+  if (!ctx || !out) return DSX_EINVAL;
+  if (!ctx->planned) return fail(ctx, DSX_ENOPLAN, "dsx_plan has not been called");
+  if (plane < 0 || plane >= ctx->last_n || level < 0 || level >= ctx->plan.L)
+    return fail(ctx, DSX_EINVAL, "plane / level index out of range");
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  const dsx::LevelPlan& lp = ctx->plan.lv[level];
+  const long long off = (stage == DSX_STAGE_APPROX) ? lp.aa_off : lp.da_off;
+  const float* src = ctx->d_ws + (size_t)plane * ctx->plan.plane_floats + off;
+  DSX_HIP(hipMemcpy2D(out, sizeof(float) * lp.w, src, sizeof(float) * lp.ld, sizeof(float) * lp.w, lp.h,
+                      hipMemcpyDeviceToHost));
+  return DSX_OK;
+}
+
+}  // extern "C"

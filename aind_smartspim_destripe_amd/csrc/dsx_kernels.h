@@ -1,0 +1,783 @@
+// dsx_kernels.h -- hand-written gfx950 kernels of the destripe path.
+//
+//   k_dwt_fwd    log(1+x) + one 2-D db3 analysis level, only the aa / da (= cH) subbands;
+//                fused: fg/bg statistic (level 1) and min/max of cH^2          
+//   k_hist       256-bin numpy-rule histogram of cH^2 per plane and level       (K2b)
+//   k_otsu       config decision + Otsu arg-max + threshold                      (K3)
+//   k_rowfilter  mask, exact row median, in-paint, FFT low-pass with the packed-index gain
+//                quirk, Delta = -(1 - mask) LP(inpainted); two rows per complex FFT (K4)
+//   k_idwt       one synthesis level of the Delta pyramid; the last level fuses
+//                (1 + x) exp(c0) + 1, flat/dark correction and the output cast    (K5, K6)
+//
+// Reference semantics: /root/reference/code/aind_smartspim_destripe/filtering.py:139-224
+// (log_space_fft_filtering), :54-88 (fg/bg statistic), :338-414 (flatfield_correction).
+#ifndef DSX_KERNELS_H
+#define DSX_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dsx_fft_core.h"
+
+namespace dsx {
+
+constexpr int kMaxLevels = 16;
+constexpr int kMaxPasses = 16;
+constexpr int kWave = 64;
+
+// db3 filter bank (PyWavelets Wavelet('db3')); rec_lo = reversed dec_lo, rec_hi = reversed dec_hi
+#define DSX_DEC_LO                                                                              \
+  {0.03522629188570953f, -0.08544127388202666f, -0.13501102001025458f, 0.45987750211849154f,   \
+   0.8068915093110925f,  0.33267055295008263f}
+#define DSX_DEC_HI                                                                              \
+  {-0.33267055295008263f, 0.8068915093110925f,  -0.45987750211849154f, -0.13501102001025458f,  \
+   0.08544127388202666f,  0.03522629188570953f}
+#define DSX_REC_LO                                                                              \
+  {0.33267055295008263f,  0.8068915093110925f,   0.45987750211849154f, -0.13501102001025458f,  \
+   -0.08544127388202666f, 0.03522629188570953f}
+#define DSX_REC_HI                                                                              \
+  {0.03522629188570953f, 0.08544127388202666f, -0.13501102001025458f, -0.45987750211849154f,   \
+   0.8068915093110925f,  -0.33267055295008263f}
+
+struct PlaneStats {
+  double sum_fg;               // sum of pixels in the foreground class (>= cut-off)
+  double sum_all;              // sum of all pixels
+  unsigned long long cnt_fg;   // pixels in the foreground class
+  unsigned long long pad_;
+};
+
+// Half-sample symmetric extension index (np.pad 'symmetric'), any distance.
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  if (i >= 0 && i < n) return i;
+  int p = 2 * n;
+  i %= p;
+  if (i < 0) i += p;
+  return i < n ? i : p - 1 - i;
+}
+
+__device__ __forceinline__ float as_f32(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ unsigned as_u32(float f) { return __float_as_uint(f); }
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Compiler-level + wavefront-scope ordering of LDS traffic inside ONE wave (no s_barrier):
+// the hardware executes a wave's LDS instructions in order; this keeps the compiler from
+// forwarding or reordering accesses across the point where other lanes' data is exchanged.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ================================================================================================
+// K1: forward level
+// ================================================================================================
+struct FwdArgs {
+  const void* in;            // IN_KIND 0/1: pixels [B][hin][win]; IN_KIND 2: unused
+  long long in_plane_stride; // elements
+  float* ws;                 // workspace base
+  long long ws_plane_stride; // floats per plane
+  long long in_off;          // IN_KIND 2: offset of aa_{l-1} inside a plane's workspace
+  int hin, win, ldin;
+  long long aa_off, da_off;
+  int h, w, ld;
+  unsigned* minmax;          // [B][L][2]: {~bits(min q), bits(max q)}, zero-initialised
+  int lvl, L;
+  PlaneStats* stats;         // level 1 only
+  float fg_cutoff;           // pixel is foreground iff (float)pixel >= fg_cutoff
+};
+
+constexpr int kFwdTH = 16, kFwdTW = 64;
+constexpr int kFwdIR = 2 * kFwdTH + 4, kFwdIC = 2 * kFwdTW + 4;  // 36 x 132 input tile
+
+template <int IN_KIND>
+__device__ __forceinline__ float fwd_load1(const FwdArgs& a, const void* base, long long off) {
+  if (IN_KIND == 0) return (float)((const uint16_t*)base)[off];
+  return ((const float*)base)[off];
+}
+
+// IN_KIND: 0 = uint16 pixels (log fused), 1 = float32 pixels (log fused), 2 = float32 aa_{l-1}
+template <int IN_KIND>
+__global__ __launch_bounds__(256) void k_dwt_fwd(FwdArgs a) {
+  constexpr int TH = kFwdTH, TW = kFwdTW, IR = kFwdIR, IC = kFwdIC;
+  __shared__ __attribute__((aligned(16))) float s_in[IR][IC];
+  __shared__ float s_v[2][TH][2][TW + 4];  // [lo|hi][row][column parity][column / 2]
+  constexpr float LO[6] = DSX_DEC_LO;
+  constexpr float HI[6] = DSX_DEC_HI;
+
+  const int tid = threadIdx.x;
+  const int plane = blockIdx.z;
+  const int i0 = blockIdx.y * TH, j0 = blockIdx.x * TW;
+  const int r_base = 2 * i0 - 4, c_base = 2 * j0 - 4;
+
+  const void* src;
+  if (IN_KIND == 2) {
+    src = a.ws + plane * a.ws_plane_stride + a.in_off;
+  } else if (IN_KIND == 0) {
+    src = (const uint16_t*)a.in + plane * a.in_plane_stride;
+  } else {
+    src = (const float*)a.in + plane * a.in_plane_stride;
+  }
+
+  double st_fg = 0.0, st_all = 0.0;
+  unsigned st_cnt = 0;
+
+  const bool vec_ok = (c_base >= 0) && (c_base + IC <= a.win) && ((a.ldin & 3) == 0);
+  if (vec_ok) {
+    constexpr int NV = IC / 4;  // 33 groups of 4 pixels
+    for (int idx = tid; idx < IR * NV; idx += 256) {
+      const int lr = idx / NV, v = idx - lr * NV;
+      const int gr_raw = r_base + lr;
+      const int gr = reflect_idx(gr_raw, a.hin);
+      const long long off = (long long)gr * a.ldin + c_base + 4 * v;
+      float f[4];
+      if (IN_KIND == 0) {
+        const uint2 raw = *(const uint2*)((const uint16_t*)src + off);
+        f[0] = (float)(raw.x & 0xFFFFu);
+        f[1] = (float)(raw.x >> 16);
+        f[2] = (float)(raw.y & 0xFFFFu);
+        f[3] = (float)(raw.y >> 16);
+      } else {
+        const float4 raw = *(const float4*)((const float*)src + off);
+        f[0] = raw.x; f[1] = raw.y; f[2] = raw.z; f[3] = raw.w;
+      }
+      if (IN_KIND != 2) {
+        const bool own_row = (lr >= 4) && (lr < 4 + 2 * TH) && (gr_raw < a.hin);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int lc = 4 * v + e;
+          if (own_row && lc >= 4 && lc < 4 + 2 * TW) {  // vec_ok: every column is inside the plane
+            st_all += (double)f[e];
+            if (f[e] >= a.fg_cutoff) { st_fg += (double)f[e]; st_cnt++; }
+          }
+          f[e] = __logf(1.0f + f[e]);
+        }
+      }
+      *(float4*)&s_in[lr][4 * v] = make_float4(f[0], f[1], f[2], f[3]);
+    }
+  } else {
+    for (int idx = tid; idx < IR * IC; idx += 256) {
+      const int lr = idx / IC, lc = idx - lr * IC;
+      const int gr_raw = r_base + lr, gc_raw = c_base + lc;
+      const int gr = reflect_idx(gr_raw, a.hin);
+      const int gc = reflect_idx(gc_raw, a.win);
+      float f = fwd_load1<IN_KIND>(a, src, (long long)gr * a.ldin + gc);
+      if (IN_KIND != 2) {
+        const bool own = (lr >= 4) && (lr < 4 + 2 * TH) && (lc >= 4) && (lc < 4 + 2 * TW) &&
+                         (gr_raw < a.hin) && (gc_raw < a.win);
+        if (own) {
+          st_all += (double)f;
+          if (f >= a.fg_cutoff) { st_fg += (double)f; st_cnt++; }
+        }
+        f = __logf(1.0f + f);
+      }
+      s_in[lr][lc] = f;
+    }
+  }
+  __syncthreads();
+
+  // axis 0 (rows): a0 = lo, d0 = hi;  out[ii] = sum_k f[k] * in[2 ii + 5 - k]
+  for (int idx = tid; idx < TH * IC; idx += 256) {
+    const int ii = idx / IC, lc = idx - ii * IC;
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float x = s_in[2 * ii + 5 - k][lc];
+      lo = fmaf(LO[k], x, lo);
+      hi = fmaf(HI[k], x, hi);
+    }
+    s_v[0][ii][lc & 1][lc >> 1] = lo;
+    s_v[1][ii][lc & 1][lc >> 1] = hi;
+  }
+  __syncthreads();
+
+  // axis 1 (columns), low-pass only: aa = lo(a0), da = lo(d0)
+  float qmin = __builtin_huge_valf(), qmax = 0.f;
+  float* aa = a.ws + plane * a.ws_plane_stride + a.aa_off;
+  float* da = a.ws + plane * a.ws_plane_stride + a.da_off;
+  for (int idx = tid; idx < TH * TW; idx += 256) {
+    const int ii = idx / TW, jj = idx - ii * TW;
+    const int i = i0 + ii, j = j0 + jj;
+    float out[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float* e = s_v[b][ii][0];
+      const float* o = s_v[b][ii][1];
+      float acc = LO[0] * o[jj + 2];
+      acc = fmaf(LO[1], e[jj + 2], acc);
+      acc = fmaf(LO[2], o[jj + 1], acc);
+      acc = fmaf(LO[3], e[jj + 1], acc);
+      acc = fmaf(LO[4], o[jj], acc);
+      acc = fmaf(LO[5], e[jj], acc);
+      out[b] = acc;
+    }
+    if (i < a.h && j < a.w) {
+      aa[(long long)i * a.ld + j] = out[0];
+      da[(long long)i * a.ld + j] = out[1];
+      const float q = out[1] * out[1];
+      qmin = fminf(qmin, q);
+      qmax = fmaxf(qmax, q);
+    }
+  }
+  qmin = wave_min_f32(qmin);
+  qmax = wave_max_f32(qmax);
+  if ((tid & 63) == 0) {
+    unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
+    if (qmin <= qmax) {  // at least one valid output in this wave
+      atomicMax(&mm[0], ~as_u32(qmin));
+      atomicMax(&mm[1], as_u32(qmax));
+    }
+  }
+  if (IN_KIND != 2) {
+    st_fg = wave_sum_f64(st_fg);
+    st_all = wave_sum_f64(st_all);
+    unsigned long long c = st_cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((tid & 63) == 0) {
+      PlaneStats* st = a.stats + plane;
+      if (st_all != 0.0) atomicAdd(&st->sum_all, st_all);
+      if (c != 0) {
+        atomicAdd(&st->sum_fg, st_fg);
+        atomicAdd(&st->cnt_fg, c);
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// K2: histogram of q = cH^2, numpy.histogram(bins=256) rule in float32
+// ================================================================================================
+struct HistArgs {
+  const float* ws;
+  long long ws_plane_stride;
+  long long da_off;
+  int h, w, ld;
+  const unsigned* minmax;
+  unsigned* hist;  // [B][L][256]
+  int lvl, L;
+  int rows_per_block;
+};
+
+__global__ __launch_bounds__(256) void k_hist(HistArgs a) {
+  __shared__ unsigned s_h[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int plane = blockIdx.y;
+  const unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
+  const float qmin = as_f32(~mm[0]), qmax = as_f32(mm[1]);
+  if (!(qmin < qmax)) return;  // constant cH^2: Otsu early-out, no histogram (block-uniform)
+  s_h[tid] = 0;
+  __syncthreads();
+  const float denom = qmax - qmin;
+  const float step = denom / 256.0f;
+  unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  const float* da = a.ws + plane * a.ws_plane_stride + a.da_off;
+  const int r0 = blockIdx.x * a.rows_per_block;
+  const int r1 = min(a.h, r0 + a.rows_per_block);
+  for (int r = r0 + wave; r < r1; r += 4) {
+    const float* row = da + (long long)r * a.ld;
+    for (int c = lane; c < a.w; c += 64) {
+      const float v = row[c];
+      const float q = v * v;
+      int idx = (int)(((q - qmin) / denom) * 256.0f);
+      idx = min(idx, 255);
+      // numpy's +-1 correction against the actual edges  edges[i] = i * step + min, edges[256] = max
+      const float e_lo = __fadd_rn(__fmul_rn((float)idx, step), qmin);
+      const float e_hi = (idx == 255) ? qmax : __fadd_rn(__fmul_rn((float)(idx + 1), step), qmin);
+      if (q < e_lo) {
+        idx -= 1;
+      } else if (idx != 255 && q >= e_hi) {
+        idx += 1;
+      }
+      idx = max(idx, 0);
+      c0 += (idx == 0);
+      c1 += (idx == 1);
+      c2 += (idx == 2);
+      c3 += (idx == 3);
+      if (idx >= 4) atomicAdd(&s_h[idx], 1u);
+    }
+  }
+  c0 = __reduce_add_sync(~0ull, c0);
+  c1 = __reduce_add_sync(~0ull, c1);
+  c2 = __reduce_add_sync(~0ull, c2);
+  c3 = __reduce_add_sync(~0ull, c3);
+  if (lane == 0) {
+    if (c0) atomicAdd(&s_h[0], c0);
+    if (c1) atomicAdd(&s_h[1], c1);
+    if (c2) atomicAdd(&s_h[2], c2);
+    if (c3) atomicAdd(&s_h[3], c3);
+  }
+  __syncthreads();
+  const unsigned n = s_h[tid];
+  if (n) atomicAdd(&a.hist[((long long)plane * a.L + a.lvl) * 256 + tid], n);
+}
+
+// ================================================================================================
+// K3: config decision + Otsu threshold (one wave per plane and level)
+// ================================================================================================
+struct OtsuArgs {
+  const PlaneStats* stats;
+  double npix;
+  double high_int;
+  const unsigned* minmax;
+  const unsigned* hist;
+  float* thr;    // [B][L]
+  float* otsu;   // [B][L]
+  int* cfg;      // [B]
+  double* means; // [B][2]
+  float max_thr[2];
+  int L;
+};
+
+__global__ __launch_bounds__(64) void k_otsu(OtsuArgs a) {
+  const int lvl = blockIdx.x, plane = blockIdx.y, lane = threadIdx.x;
+  // decision of filtering.py:459-462 (empty class -> mean 0.0)
+  const PlaneStats st = a.stats[plane];
+  const double cnt_fg = (double)st.cnt_fg, cnt_bg = a.npix - cnt_fg;
+  const double fore = cnt_fg > 0 ? st.sum_fg / cnt_fg : 0.0;
+  const double back = cnt_bg > 0 ? (st.sum_all - st.sum_fg) / cnt_bg : 0.0;
+  const int cfg = (fore > back && fore > a.high_int) ? 1 : 0;
+  if (lvl == 0 && lane == 0) {
+    a.cfg[plane] = cfg;
+    a.means[2 * plane] = fore;
+    a.means[2 * plane + 1] = back;
+  }
+  const long long pl = (long long)plane * a.L + lvl;
+  const unsigned* mm = a.minmax + pl * 2;
+  const float q_lo = as_f32(~mm[0]), q_hi = as_f32(mm[1]);
+  double otsu;
+  if (!(q_lo < q_hi)) {
+    otsu = (double)q_lo;  // all values equal: threshold_otsu returns that value
+  } else {
+    const double first = (double)q_lo, last = (double)q_hi;
+    const double step = (last - first) / 256.0;
+    const unsigned* h = a.hist + pl * 256;
+    double cnt[4], cb[4], bc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = 4 * lane + i;
+      const double e0 = first + g * step;
+      const double e1 = (g == 255) ? last : first + (g + 1) * step;
+      bc[i] = 0.5 * (e0 + e1);
+      cnt[i] = (double)h[g];
+      cb[i] = cnt[i] * bc[i];
+    }
+    const double lw = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    const double ls = cb[0] + cb[1] + cb[2] + cb[3];
+    double w_inc = lw, s_inc = ls, r_inc = ls;  // inclusive scans: forward counts, forward cb, reverse cb
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double tw_ = __shfl_up(w_inc, o);
+      const double ts_ = __shfl_up(s_inc, o);
+      const double tr_ = __shfl_down(r_inc, o);
+      if (lane >= o) { w_inc += tw_; s_inc += ts_; }
+      if (lane + o < 64) r_inc += tr_;
+    }
+    const double total_w = __shfl(w_inc, 63);
+    double w1 = w_inc - lw, s1 = s_inc - ls;  // exclusive prefixes
+    double s2 = r_inc;                         // sum of cb over bins >= 4 * lane
+    double best = -1.0;
+    int best_g = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = 4 * lane + i;
+      w1 += cnt[i];
+      s1 += cb[i];
+      s2 -= cb[i];  // now: sum over bins > g
+      if (g < 255) {
+        const double w2 = total_w - w1;
+        const double m1 = s1 / w1, m2 = s2 / w2;
+        const double d = m1 - m2;
+        const double var = w1 * w2 * d * d;
+        if (var > best) { best = var; best_g = g; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o);
+      const int og = __shfl_xor(best_g, o);
+      if (ob > best || (ob == best && og < best_g)) { best = ob; best_g = og; }
+    }
+    const double e0 = first + best_g * step;
+    const double e1 = (best_g == 255) ? last : first + (best_g + 1) * step;
+    otsu = 0.5 * (e0 + e1);
+  }
+  if (lane == 0) {
+    const double t = fmin(otsu >= 0 ? sqrt(otsu) : 0.0, (double)a.max_thr[cfg]);
+    a.otsu[pl] = (float)otsu;
+    a.thr[pl] = (float)t;
+  }
+}
+
+// ================================================================================================
+// K4: row filter
+// ================================================================================================
+struct RowArgs {
+  float* ws;
+  long long ws_plane_stride;
+  long long da_off;
+  int h, w, ld;
+  const float* thr;  // [B][L]
+  const int* cfg;    // [B]
+  int lvl, L;
+  int lvl_active[2];  // number of levels each config filters (levels >= that get Delta = 0)
+  int M, K;
+  int npass;
+  int radix[kMaxPasses];
+  const float2* tw;    // [M] exp(-2 pi i t / M)
+  const float2* g[2];  // per config: G1[M] then G2[M]
+  float inv_M;
+};
+
+__device__ __forceinline__ unsigned f32_key(float v) {
+  const unsigned b = as_u32(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) {
+  return as_f32((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+template <int R, int CPL>
+__device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int M, int s, float inv_s,
+                                         int lane) {
+  constexpr int MAXB = (CPL + R - 1) / R;
+  const int nb = M / R;
+  float2 v[MAXB][R];
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int b = lane + kWave * i;
+    if (b < nb) dsx_bfly_load<R>(buf, b, nb, v[i]);
+  }
+  // LDS operations of one wave execute in program order: every read above precedes the writes below
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int b = lane + kWave * i;
+    if (b < nb) dsx_bfly_store<R>(buf, tw, b, s, inv_s, v[i]);
+  }
+  wave_sync();
+}
+
+template <int CPL>
+__device__ __forceinline__ void fft_pass_generic(float2* buf, const float2* tw, int M, int s,
+                                                 float inv_s, int R, int lane) {
+  float2 acc[CPL];
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int o = lane + kWave * i;
+    acc[i] = make_float2(0.f, 0.f);
+    if (o < M) acc[i] = dsx_generic_output(buf, tw, o, M, s, inv_s, R);
+  }
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int o = lane + kWave * i;
+    if (o < M) buf[o] = acc[i];
+  }
+  wave_sync();
+}
+
+template <int CPL>
+__device__ __forceinline__ void fft_run(float2* buf, const float2* tw, const RowArgs& a, int lane) {
+  int s = 1;
+  for (int pi = 0; pi < a.npass; ++pi) {
+    const int R = a.radix[pi];
+    const float inv_s = 1.0f / (float)s;
+    switch (R) {
+      case 2: fft_pass<2, CPL>(buf, tw, a.M, s, inv_s, lane); break;
+      case 3: fft_pass<3, CPL>(buf, tw, a.M, s, inv_s, lane); break;
+      case 4: fft_pass<4, CPL>(buf, tw, a.M, s, inv_s, lane); break;
+      case 5: fft_pass<5, CPL>(buf, tw, a.M, s, inv_s, lane); break;
+      default: fft_pass_generic<CPL>(buf, tw, a.M, s, inv_s, R, lane); break;
+    }
+    s *= R;
+  }
+}
+
+// One wave per pair of rows.  CPL = complex values per lane = ceil(M / 64).
+template <int CPL>
+__global__ __launch_bounds__(256) void k_rowfilter(RowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = a.M, N = a.w, K = a.K;
+  float2* s_tw = dsx_smem;
+  float2* buf = dsx_smem + (long long)M * (1 + wave);
+  for (int i = tid; i < M; i += 256) s_tw[i] = a.tw[i];
+  __syncthreads();  // the only block-wide barrier: afterwards every wave works on its own rows
+
+  const int pair = blockIdx.x * 4 + wave;
+  const int npairs = (a.h + 1) >> 1;
+  if (pair >= npairs) return;
+  const int plane = blockIdx.y;
+  const int r0 = 2 * pair;
+  const bool has_b = (r0 + 1) < a.h;
+  const int cfg = a.cfg[plane];
+  float* rowa = a.ws + plane * a.ws_plane_stride + a.da_off + (long long)r0 * a.ld;
+  float* rowb = rowa + a.ld;
+
+  if (a.lvl >= a.lvl_active[cfg]) {  // this config does not filter this level: Delta = 0
+    for (int n = lane; n < N; n += kWave) {
+      rowa[n] = 0.f;
+      if (has_b) rowb[n] = 0.f;
+    }
+    return;
+  }
+  const float thr = a.thr[(long long)plane * a.L + a.lvl];
+
+  constexpr int E = CPL;
+  unsigned ka[E], kb[E];
+  unsigned long long maska = 0, maskb = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int n = lane + kWave * e;
+    ka[e] = 0xFFFFFFFFu;
+    kb[e] = 0xFFFFFFFFu;
+    if (n < N) {
+      const float va = rowa[n];
+      const float vb = has_b ? rowb[n] : 0.f;
+      const bool ma = fabsf(va) > thr, mb = fabsf(vb) > thr;
+      if (ma) maska |= (1ull << e);
+      if (mb) maskb |= (1ull << e);
+      ka[e] = f32_key(ma ? 0.f : va);  // background: masked entries are zeroed (filtering.py:197)
+      kb[e] = f32_key(mb ? 0.f : vb);
+    }
+  }
+
+  // exact row medians (np.median, filtering.py:201): k-th smallest by bitwise bisection on keys
+  const unsigned k1 = (unsigned)(N - 1) >> 1;
+  unsigned ra = 0, rb = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned ta = ra | (1u << bit), tb = rb | (1u << bit);
+    unsigned c = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      c += (ka[e] < ta) ? 1u : 0u;
+      c += (kb[e] < tb) ? 0x10000u : 0u;
+    }
+    c = __reduce_add_sync(~0ull, c);
+    if ((c & 0xFFFFu) <= k1) ra = ta;
+    if ((c >> 16) <= k1) rb = tb;
+  }
+  float meda = key_f32(ra), medb = key_f32(rb);
+  if ((N & 1) == 0) {
+    // second middle order statistic: the smallest element above the first one unless it is tied.
+    // The cross-lane minimum goes through an LDS atomic (once per row pair): shuffle-based
+    // reductions at this point crash ROCm 7.2's instruction selection for gfx950.
+    unsigned c = 0, mna = 0xFFFFFFFFu, mnb = 0xFFFFFFFFu;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      c += (ka[e] <= ra) ? 1u : 0u;
+      c += (kb[e] <= rb) ? 0x10000u : 0u;
+      if (ka[e] > ra) mna = min(mna, ka[e]);
+      if (kb[e] > rb) mnb = min(mnb, kb[e]);
+    }
+    c = __reduce_add_sync(~0ull, c);
+    unsigned* s_mn = (unsigned*)buf;  // the row buffer is not in use yet
+    if (lane == 0) { s_mn[0] = 0xFFFFFFFFu; s_mn[1] = 0xFFFFFFFFu; }
+    wave_sync();
+    atomicMin(&s_mn[0], mna);
+    atomicMin(&s_mn[1], mnb);
+    wave_sync();
+    mna = s_mn[0];
+    mnb = s_mn[1];
+    wave_sync();
+    const float v2a = ((c & 0xFFFFu) > k1 + 1) ? meda : key_f32(mna);
+    const float v2b = ((c >> 16) > k1 + 1) ? medb : key_f32(mnb);
+    meda = 0.5f * (meda + v2a);
+    medb = 0.5f * (medb + v2b);
+  }
+
+  // The medians are wave-uniform (SGPR); ROCm 7.2's instruction selection crashes when they flow
+  // into the selects / LDS stores below, so pin them into VGPRs.
+  asm volatile("" : "+v"(meda), "+v"(medb));
+
+  // in-painted rows -> complex buffer u[m] = x[(m - K) mod N], m in [0, N + 2K]; zero above
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int n = lane + kWave * e;
+    if (n < N) {
+      const float xa = ((maska >> e) & 1ull) ? meda : key_f32(ka[e]);
+      const float xb = ((maskb >> e) & 1ull) ? medb : key_f32(kb[e]);
+      const float2 z = make_float2(xa, xb);
+      buf[K + n] = z;
+      if (K > 0) {
+        if (n <= K) buf[K + N + n] = z;
+        if (n >= N - K) buf[n - (N - K)] = z;
+      }
+    }
+  }
+  if (K > 0) {
+    for (int m = N + 2 * K + 1 + lane; m < M; m += kWave) buf[m] = make_float2(0.f, 0.f);
+  }
+  wave_sync();
+
+  fft_run<CPL>(buf, s_tw, a, lane);
+
+  // V[k] = G1[k] U[k] + G2[k] U[(M - k) mod M], stored re/im-swapped for the inverse transform
+  {
+    const float2* g1 = a.g[cfg];
+    const float2* g2 = g1 + M;
+    float2 u[CPL], ur[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int k = lane + kWave * i;
+      if (k < M) {
+        u[i] = buf[k];
+        ur[i] = buf[k == 0 ? 0 : M - k];
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int k = lane + kWave * i;
+      if (k < M) {
+        const float2 v = dsx_add(dsx_mul(g1[k], u[i]), dsx_mul(g2[k], ur[i]));
+        buf[k] = make_float2(v.y, v.x);
+      }
+    }
+    wave_sync();
+  }
+
+  fft_run<CPL>(buf, s_tw, a, lane);
+
+  // buf = swap(M * LP): row a <- .y, row b <- .x ; Delta = -(1 - mask) * LP  (filtering.py:215-217)
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int n = lane + kWave * e;
+    if (n < N) {
+      const float2 y = buf[K + n];
+      rowa[n] = ((maska >> e) & 1ull) ? 0.f : -y.y * a.inv_M;
+      if (has_b) rowb[n] = ((maskb >> e) & 1ull) ? 0.f : -y.x * a.inv_M;
+    }
+  }
+}
+
+// ================================================================================================
+// K5 / K6: synthesis level of the Delta pyramid; FINAL fuses (1 + x) exp(c0) + 1, shading, cast
+// ================================================================================================
+struct InvArgs {
+  float* ws;
+  long long ws_plane_stride;
+  long long c_off, d_off;  // c_l (approximation buffer of level l) and Delta_l
+  int hc, wc, ldc;
+  int has_c;               // 0 at the coarsest level (c_L == 0)
+  int has_pyr;             // 0 when no level runs at all (level == 0: result is x + 2)
+  long long out_off;       // c_{l-1} destination inside the plane workspace (non-final)
+  int hout, wout, ldout;
+  // final level only
+  const void* img;
+  long long img_plane_stride;
+  int H, W;
+  void* out;
+  long long out_plane_stride;
+  int out_dtype;            // 0 = uint16, 1 = float32
+  const float* flat;        // [hout][wout] or null
+  const float* dark;        // [dark_h][dark_ld] cropped to the plane, or null
+  int dark_ld;
+};
+
+constexpr int kInvTH = 32, kInvTW = 64;
+constexpr int kInvCR = kInvTH / 2 + 2, kInvCQ = kInvTW / 2 + 2;  // 18 x 34 coefficient tile
+
+__device__ __forceinline__ float finish_px(const InvArgs& a, float c0, float x, int gy, int gx) {
+  // exp(log(1 + x) + c0) + 1  (filtering.py:222: plus one, not minus)
+  float v = fmaf(1.0f + x, __expf(c0), 1.0f);
+  if (a.flat != nullptr) {  // flatfield_correction, filtering.py:399-412
+    const float d = a.dark[(long long)gy * a.dark_ld + gx];
+    v = (v > d) ? (v - d) : 0.f;
+    v = v / a.flat[(long long)gy * a.wout + gx];
+    v = fminf(fmaxf(v, 0.f), 65535.f);
+  }
+  return v;
+}
+
+// FINAL: 0 = pyramid level, 1 = last level with uint16 pixels, 2 = last level with float32 pixels
+template <int FINAL>
+__global__ __launch_bounds__(256) void k_idwt(InvArgs a) {
+  constexpr int TH = kInvTH, TW = kInvTW, CR = kInvCR, CQ = kInvCQ;
+  __shared__ float s_c[CR][CQ + 1], s_d[CR][CQ + 1];
+  __shared__ float s_a0[CR][TW], s_d0[CR][TW];
+  constexpr float RL[6] = DSX_REC_LO;
+  constexpr float RH[6] = DSX_REC_HI;
+  const int tid = threadIdx.x;
+  const int plane = blockIdx.z;
+  const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const int p0 = y0 >> 1, q0 = x0 >> 1;
+  const float* cbuf = a.ws + plane * a.ws_plane_stride + a.c_off;
+  const float* dbuf = a.ws + plane * a.ws_plane_stride + a.d_off;
+
+  if (FINAL == 0 || a.has_pyr) {
+    for (int idx = tid; idx < CR * CQ; idx += 256) {
+      const int rr = idx / CQ, cc = idx - rr * CQ;
+      const int gp = p0 + rr, gq = q0 + cc;
+      const bool ok = (gp < a.hc) && (gq < a.wc);
+      s_c[rr][cc] = (ok && a.has_c) ? cbuf[(long long)gp * a.ldc + gq] : 0.f;
+      s_d[rr][cc] = ok ? dbuf[(long long)gp * a.ldc + gq] : 0.f;
+    }
+    __syncthreads();
+    // axis 1: out[2 q + b] = sum_j in[q + j] * rec_lo[4 - 2 j + b]   (ad = dd = 0: low-pass only)
+    for (int idx = tid; idx < CR * TW; idx += 256) {
+      const int rr = idx / TW, xx = idx - rr * TW;
+      const int qq = xx >> 1, b = xx & 1;
+      const float l0 = b ? RL[5] : RL[4], l1 = b ? RL[3] : RL[2], l2 = b ? RL[1] : RL[0];
+      s_a0[rr][xx] = fmaf(s_c[rr][qq], l0, fmaf(s_c[rr][qq + 1], l1, s_c[rr][qq + 2] * l2));
+      s_d0[rr][xx] = fmaf(s_d[rr][qq], l0, fmaf(s_d[rr][qq + 1], l1, s_d[rr][qq + 2] * l2));
+    }
+    __syncthreads();
+  }
+
+  for (int idx = tid; idx < TH * TW; idx += 256) {
+    const int yy = idx / TW, xx = idx - yy * TW;
+    const int gy = y0 + yy, gx = x0 + xx;
+    if (gy >= a.hout || gx >= a.wout) continue;
+    float v = 0.f;
+    if (FINAL == 0 || a.has_pyr) {
+      const int pp = yy >> 1, b = yy & 1;
+      const float l0 = b ? RL[5] : RL[4], l1 = b ? RL[3] : RL[2], l2 = b ? RL[1] : RL[0];
+      const float h0 = b ? RH[5] : RH[4], h1 = b ? RH[3] : RH[2], h2 = b ? RH[1] : RH[0];
+      v = s_a0[pp][xx] * l0;
+      v = fmaf(s_a0[pp + 1][xx], l1, v);
+      v = fmaf(s_a0[pp + 2][xx], l2, v);
+      v = fmaf(s_d0[pp][xx], h0, v);
+      v = fmaf(s_d0[pp + 1][xx], h1, v);
+      v = fmaf(s_d0[pp + 2][xx], h2, v);
+    }
+    if (FINAL == 0) {
+      a.ws[plane * a.ws_plane_stride + a.out_off + (long long)gy * a.ldout + gx] = v;
+    } else {
+      // an odd plane grows by one row/column: the reconstructed log image there is the
+      // half-sample symmetric extension, i.e. the replicated edge pixel
+      const int sy = min(gy, a.H - 1), sx = min(gx, a.W - 1);
+      float x;
+      if (FINAL == 1) {
+        x = (float)((const uint16_t*)a.img)[plane * a.img_plane_stride + (long long)sy * a.W + sx];
+      } else {
+        x = ((const float*)a.img)[plane * a.img_plane_stride + (long long)sy * a.W + sx];
+      }
+      const float r = finish_px(a, v, x, gy, gx);
+      const long long o = plane * a.out_plane_stride + (long long)gy * a.wout + gx;
+      if (a.out_dtype == 0) {
+        ((uint16_t*)a.out)[o] = (uint16_t)(int)fminf(fmaxf(r, 0.f), 65535.f);
+      } else {
+        ((float*)a.out)[o] = r;
+      }
+    }
+  }
+}
+
+}  // namespace dsx
+#endif  // DSX_KERNELS_H

@@ -1,0 +1,241 @@
+// dsx_plan.h -- host-side planning: level geometry, workspace layout, FFT factorisation and the
+// spectral gain tables of the row filter (DESIGN.md sections 2 and 3.4).  Pure C++ (no HIP), so
+// that tests/test_plan_host.py can exercise it with g++.
+//
+// Reference semantics restated here:
+//   level selection          pywt.wavedec2 / dwt_max_level        (call site filtering.py:176)
+//   width_fraction, s        filtering.py:180, 213
+//   notch gains g = 1 - e    filtering.py:91-115, applied in fftpack packed order (:206-215)
+#ifndef DSX_PLAN_H
+#define DSX_PLAN_H
+
+#include <math.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+namespace dsx {
+
+constexpr int kPlanMaxLevels = 16;
+constexpr int kPlanMaxPasses = 16;
+constexpr int kFilterLen = 6;           // db3
+constexpr int kMaxFftLen = 64 * 36;     // largest row-filter kernel instantiation (CPL = 36)
+
+struct HostCfg {
+  int level;  // -1 == maximum
+  double sigma;
+  double max_threshold;
+};
+
+struct C32 {
+  float re, im;
+};
+
+struct LevelPlan {
+  int hin, win, ldin;  // input of the analysis level (level 0: the plane itself)
+  int h, w, ld;        // coefficient shape and row pitch (multiple of 4 floats)
+  long long aa_off, da_off;
+  // row filter
+  int M, K;
+  int npass;
+  int radix[kPlanMaxPasses];
+  long long tw_off;    // C32 offset of the twiddles in the constant blob
+  long long g_off[2];  // C32 offset of G1[M] (followed by G2[M]) per config
+};
+
+struct Plan {
+  int H = 0, W = 0, Hout = 0, Wout = 0;
+  int L = 0;            // levels run (max over both configs)
+  int cfg_levels[2] = {0, 0};
+  LevelPlan lv[kPlanMaxLevels];
+  long long plane_floats = 0;  // workspace floats per plane
+  std::vector<C32> consts;     // twiddles + gain tables
+};
+
+inline int dwt_max_level(int n) {
+  if (n < kFilterLen - 1) return 0;
+  int l = (int)floor(log2((double)n / (kFilterLen - 1.0)));
+  return l < 0 ? 0 : l;
+}
+
+inline std::vector<int> factorize(int n) {
+  std::vector<int> r;
+  while (n % 4 == 0) { r.push_back(4); n /= 4; }
+  while (n % 2 == 0) { r.push_back(2); n /= 2; }
+  while (n % 3 == 0) { r.push_back(3); n /= 3; }
+  while (n % 5 == 0) { r.push_back(5); n /= 5; }
+  for (int p = 7; n > 1; p += 2) {
+    while (n % p == 0) { r.push_back(p); n /= p; }
+  }
+  return r;
+}
+
+// relative cost of one pass per element (register butterflies vs the generic O(R) pass)
+inline double pass_cost(int r) {
+  switch (r) {
+    case 2: return 10.0;
+    case 3: return 13.3;
+    case 4: return 12.0;
+    case 5: return 16.0;
+    default: return 8.0 + 10.0 * r;
+  }
+}
+inline double fft_cost(int m) {
+  double c = 0;
+  for (int r : factorize(m)) c += pass_cost(r);
+  return c * m;
+}
+
+// LP gains in fftpack packed order, folded to the complex bins of a length-n transform:
+//   e[j] = exp(-j^2 / (2 s^2));  ep[k] = (e[2k-1] + e[2k]) / 2,  em[k] = (e[2k-1] - e[2k]) / 2
+//   (1 <= k <= (n-1)/2, mirrored to n-k);  ep[0] = e[0] = 1;  even n: ep[n/2] = e[n-1], em = 0.
+inline void packed_gains(int n, double s, std::vector<double>& ep, std::vector<double>& em) {
+  ep.assign(n, 0.0);
+  em.assign(n, 0.0);
+  auto e = [&](int j) { return exp(-((double)j * (double)j) / (2.0 * s * s)); };
+  ep[0] = e(0);
+  for (int k = 1; k <= (n - 1) / 2; ++k) {
+    const double ea = e(2 * k - 1), eb = e(2 * k);
+    ep[k] = ep[n - k] = 0.5 * (ea + eb);
+    em[k] = em[n - k] = 0.5 * (ea - eb);
+  }
+  if (n % 2 == 0 && n >= 2) {
+    ep[n / 2] = e(n - 1);
+    em[n / 2] = 0.0;
+  }
+}
+
+// real even sequence -> real even inverse DFT:  h[d] = (1/n) sum_k g[k] cos(2 pi k d / n)
+inline std::vector<double> idft_even(const std::vector<double>& g) {
+  const int n = (int)g.size();
+  std::vector<double> c(n), h(n);
+  for (int t = 0; t < n; ++t) c[t] = cos(2.0 * M_PI * t / n);
+  for (int d = 0; d < n; ++d) {
+    double acc = 0;
+    for (int k = 0; k < n; ++k) acc += g[k] * c[(int)(((long long)k * d) % n)];
+    h[d] = acc / n;
+  }
+  return h;
+}
+
+// Build the plan.  Returns "" or an error text.
+inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p) {
+  if (H < 1 || W < 1) return "plane must be at least 1x1";
+  for (int c = 0; c < 2; ++c) {
+    if (!(cfg[c].sigma > 0)) return "sigma must be positive";
+    if (cfg[c].level < -1) return "Level value is too low . Minimum level is 0.";
+  }
+  p = Plan();
+  p.H = H;
+  p.W = W;
+  const int max_level = std::min(dwt_max_level(H), dwt_max_level(W));
+  for (int c = 0; c < 2; ++c) p.cfg_levels[c] = cfg[c].level < 0 ? max_level : cfg[c].level;
+  p.L = std::max(p.cfg_levels[0], p.cfg_levels[1]);
+  if (p.L > kPlanMaxLevels) return "too many decomposition levels";
+  if ((H & 1) || (W & 1)) {
+    // an odd plane grows by one row/column iff at least one level runs; both configs must agree
+    if ((p.cfg_levels[0] == 0) != (p.cfg_levels[1] == 0))
+      return "odd plane: both configs must either run levels or none (result shapes differ)";
+  }
+  p.Hout = (p.L > 0) ? H + (H & 1) : H;
+  p.Wout = (p.L > 0) ? W + (W & 1) : W;
+
+  long long off = 0;
+  int hin = H, win = W, ldin = W;
+  const double min_hw = (double)std::min(H, W);
+  for (int l = 0; l < p.L; ++l) {
+    LevelPlan& lp = p.lv[l];
+    lp.hin = hin; lp.win = win; lp.ldin = ldin;
+    lp.h = (hin + kFilterLen - 1) / 2;
+    lp.w = (win + kFilterLen - 1) / 2;
+    lp.ld = (lp.w + 3) & ~3;
+    lp.aa_off = off; off += (long long)lp.h * lp.ld;
+    lp.da_off = off; off += (long long)lp.h * lp.ld;
+    hin = lp.h; win = lp.w; ldin = lp.ld;
+
+    // ---- row filter plan for this level -----------------------------------------------------
+    const int n = lp.w;
+    std::vector<double> ep[2], em[2], h1[2], h2[2];
+    for (int c = 0; c < 2; ++c) {
+      const double s = lp.h * (cfg[c].sigma / min_hw);  // filtering.py:180, 213
+      packed_gains(n, s, ep[c], em[c]);
+    }
+    // Candidates: (a) the direct length-n transform (generic O(R) passes for prime factors > 5);
+    // (b) the exact embedding of the length-n circular operator in a 2-3-5-smooth length
+    //     M >= n + 2K + 1 with a periodic halo of K = floor(n / 2) samples on both sides.
+    //     (The spatial kernels of ep / em decay only like 1/d^2 -- the packed-index gains are not
+    //      smooth at k = 0 -- so the halo cannot be truncated below n / 2.)
+    int best_m = n, best_k = 0;
+    double best_cost = fft_cost(n);
+    if (n > kMaxFftLen) best_cost = 1e300;
+    if (n >= 8) {
+      const int K = n / 2;
+      const int need = n + 2 * K + 1;
+      for (int m = need; m <= std::min(2 * need, kMaxFftLen); ++m) {
+        int t = m;
+        for (int q : {2, 3, 5}) while (t % q == 0) t /= q;
+        if (t != 1) continue;
+        const double c = fft_cost(m);
+        if (c < best_cost) { best_cost = c; best_m = m; best_k = K; }
+      }
+    }
+    if (best_k > 0) {
+      for (int c = 0; c < 2; ++c) {
+        h1[c] = idft_even(ep[c]);
+        h2[c] = idft_even(em[c]);
+      }
+    }
+    if (best_cost >= 1e300) return "plane too wide for the row-filter kernels";
+    lp.M = best_m;
+    lp.K = best_k;
+    const std::vector<int> rad = factorize(best_m);
+    if ((int)rad.size() > kPlanMaxPasses) return "too many FFT passes";
+    lp.npass = (int)rad.size();
+    for (int i = 0; i < lp.npass; ++i) lp.radix[i] = rad[i];
+    if (lp.npass == 0) { lp.npass = 0; }  // M == 1: no pass, transform is the identity
+
+    const int M = lp.M;
+    lp.tw_off = (long long)p.consts.size();
+    for (int t = 0; t < M; ++t) {
+      const double a = -2.0 * M_PI * t / M;
+      p.consts.push_back(C32{(float)cos(a), (float)sin(a)});
+    }
+    for (int c = 0; c < 2; ++c) {
+      lp.g_off[c] = (long long)p.consts.size();
+      std::vector<C32> g1(M), g2(M);
+      if (lp.K == 0) {  // direct: G1 = ep, G2 = em (real)
+        for (int k = 0; k < M; ++k) {
+          g1[k] = C32{(float)ep[c][k], 0.f};
+          g2[k] = C32{(float)em[c][k], 0.f};
+        }
+      } else {
+        const int Kc = lp.K, cshift = n + 2 * Kc;
+        std::vector<double> cs(M), sn(M);
+        for (int t = 0; t < M; ++t) { cs[t] = cos(2.0 * M_PI * t / M); sn[t] = sin(2.0 * M_PI * t / M); }
+        for (int k = 0; k < M; ++k) {
+          double a1 = h1[c][0], a2 = h2[c][0];
+          for (int d = 1; d <= Kc; ++d) {
+            // h[-d] = h[n - d] = h[d]; for even n the lag n/2 is one circular lag: half weight each side
+            const double wgt = (2 * d == n) ? 1.0 : 2.0;
+            const double cc = wgt * cs[(int)(((long long)d * k) % M)];
+            a1 += h1[c][d] * cc;
+            a2 += h2[c][d] * cc;
+          }
+          const int t = (int)(((long long)cshift * k) % M);
+          g1[k] = C32{(float)a1, 0.f};
+          g2[k] = C32{(float)(a2 * cs[t]), (float)(-a2 * sn[t])};  // * exp(-2 pi i c k / M)
+        }
+      }
+      p.consts.insert(p.consts.end(), g1.begin(), g1.end());
+      p.consts.insert(p.consts.end(), g2.begin(), g2.end());
+    }
+  }
+  p.plane_floats = (off + 3) & ~3LL;
+  if (p.plane_floats == 0) p.plane_floats = 4;
+  return "";
+}
+
+}  // namespace dsx
+#endif  // DSX_PLAN_H

@@ -1,0 +1,330 @@
+"""ctypes binding of ``libdsx_hip.so`` (C ABI in ``include/dsx.h``).
+
+No GPU array library is involved: device memory, copies, streams and timing all go through the
+C ABI.  The engine has NO CPU fallback -- if the library is missing or no MI355X is visible the
+constructor raises :class:`DsxError`.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libdsx_hip.so")
+
+DSX_U16, DSX_F32 = 0, 1
+DSX_WAVELET_DB3 = 3
+STAGE_APPROX, STAGE_DETAIL = 0, 1
+_ERRORS = {-1: "DSX_EINVAL", -2: "DSX_ENOPLAN", -3: "DSX_EHIP", -4: "DSX_ENOMEM", -5: "DSX_ELIMIT"}
+
+# every symbol include/dsx.h declares (tests/test_cabi_symbols.py checks the list against the header)
+EXPORTED_SYMBOLS = [
+    "dsx_init", "dsx_destroy", "dsx_last_error", "dsx_device_count", "dsx_plan", "dsx_plan_info",
+    "dsx_set_shading_device", "dsx_constants_device", "dsx_run_host", "dsx_run_device", "dsx_sync",
+    "dsx_malloc", "dsx_free", "dsx_memcpy_h2d", "dsx_memcpy_d2h", "dsx_memcpy_d2d",
+    "dsx_timer_start", "dsx_timer_stop", "dsx_profile_enable", "dsx_profile_read",
+    "dsx_get_stats", "dsx_get_thresholds", "dsx_get_level", "dsx_set_stop_after",
+]  # fmt: skip
+
+
+class DsxError(RuntimeError):
+    """Error reported by the HIP engine (code + message of ``dsx_last_error``)."""
+
+    def __init__(self, code, message):
+        super().__init__("{} ({}): {}".format(_ERRORS.get(code, "DSX_E?"), code, message))
+        self.code = code
+        self.message = message
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [
+        ("wavelet", ctypes.c_int32),
+        ("level", ctypes.c_int32),
+        ("sigma", ctypes.c_float),
+        ("max_threshold", ctypes.c_float),
+    ]
+
+
+class _PlanInfo(ctypes.Structure):
+    _fields_ = [
+        ("height", ctypes.c_int32),
+        ("width", ctypes.c_int32),
+        ("out_height", ctypes.c_int32),
+        ("out_width", ctypes.c_int32),
+        ("levels", ctypes.c_int32),
+        ("level_h", ctypes.c_int32 * 16),
+        ("level_w", ctypes.c_int32 * 16),
+        ("fft_len", ctypes.c_int32 * 16),
+        ("fft_halo", ctypes.c_int32 * 16),
+        ("max_batch", ctypes.c_int32),
+        ("workspace_bytes", ctypes.c_uint64),
+    ]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load ``libdsx_hip.so``; raises ``DsxError`` if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise DsxError(
+            -3,
+            "{} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the destripe engine has no CPU fallback)".format(p),
+        )
+    lib = ctypes.CDLL(p)
+    vp, i32, f32p = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float)
+    lib.dsx_init.argtypes = [i32, ctypes.POINTER(vp)]
+    lib.dsx_destroy.argtypes = [vp]
+    lib.dsx_destroy.restype = None
+    lib.dsx_last_error.argtypes = [vp]
+    lib.dsx_last_error.restype = ctypes.c_char_p
+    lib.dsx_device_count.argtypes = []
+    lib.dsx_plan.argtypes = [vp, i32, i32, i32, ctypes.POINTER(_Cfg), ctypes.POINTER(_Cfg),
+                             ctypes.c_double, vp, vp, i32, i32]  # fmt: skip
+    lib.dsx_plan_info.argtypes = [vp, ctypes.POINTER(_PlanInfo)]
+    lib.dsx_set_shading_device.argtypes = [vp, vp, vp, i32, i32]
+    lib.dsx_constants_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+    lib.dsx_run_host.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    lib.dsx_run_device.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    lib.dsx_sync.argtypes = [vp]
+    lib.dsx_malloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.dsx_free.argtypes = [vp, vp]
+    lib.dsx_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    lib.dsx_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    lib.dsx_memcpy_d2d.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    lib.dsx_timer_start.argtypes = [vp]
+    lib.dsx_timer_stop.argtypes = [vp, f32p]
+    lib.dsx_profile_enable.argtypes = [vp, i32]
+    lib.dsx_profile_read.argtypes = [vp, i32, f32p, ctypes.POINTER(ctypes.c_int32),
+                                     ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i32)]  # fmt: skip
+    lib.dsx_get_stats.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double),
+                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]  # fmt: skip
+    lib.dsx_get_thresholds.argtypes = [vp, i32, i32, f32p, f32p]
+    lib.dsx_get_level.argtypes = [vp, i32, i32, i32, vp]
+    lib.dsx_set_stop_after.argtypes = [vp, i32]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("dsx_destroy", "dsx_last_error"):
+            fn.restype = ctypes.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _as_cfg(cfg):
+    """Reference config dict {"wavelet","level","sigma","max_threshold"} -> C struct."""
+    wavelet = cfg.get("wavelet", "db3")
+    if wavelet != "db3":
+        raise ValueError("only wavelet 'db3' is implemented (production setting, run_capsule.py:374-390)")
+    level = cfg.get("level", 0)
+    return _Cfg(DSX_WAVELET_DB3, -1 if level is None else int(level), float(cfg.get("sigma", 64)),
+                float(cfg.get("max_threshold", 4)))  # fmt: skip
+
+
+class DeviceBuffer:
+    """A device allocation owned by an engine."""
+
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        engine._check(engine._lib.dsx_malloc(engine._ctx, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr is not None and self.engine._ctx is not None:
+            self.engine._lib.dsx_free(self.engine._ctx, ctypes.c_void_p(self.ptr))
+        self.ptr = None
+
+    def upload(self, array, offset=0):
+        a = np.ascontiguousarray(array)
+        assert offset + a.nbytes <= self.nbytes
+        self.engine._check(
+            self.engine._lib.dsx_memcpy_h2d(self.engine._ctx, ctypes.c_void_p(self.ptr + offset),
+                                            a.ctypes.data_as(ctypes.c_void_p), a.nbytes)
+        )  # fmt: skip
+
+    def download(self, shape, dtype, offset=0):
+        out = np.empty(shape, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        self.engine._check(
+            self.engine._lib.dsx_memcpy_d2h(self.engine._ctx, out.ctypes.data_as(ctypes.c_void_p),
+                                            ctypes.c_void_p(self.ptr + offset), out.nbytes)
+        )  # fmt: skip
+        return out
+
+
+def _dtype_code(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.uint16:
+        return DSX_U16
+    if dtype == np.float32:
+        return DSX_F32
+    raise ValueError("planes must be uint16 or float32, got {}".format(dtype))
+
+
+class DestripeEngine:
+    """One context on one GPU: ``plan()`` once per plane geometry / config pair, then ``run()``."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        ctx = ctypes.c_void_p()
+        rc = self._lib.dsx_init(int(device), ctypes.byref(ctx))
+        if rc != 0:
+            msg = self._lib.dsx_last_error(None)
+            raise DsxError(rc, msg.decode() if msg else "dsx_init failed")
+        self._ctx = ctx
+        self.device = int(device)
+        self.info = None
+
+    # -- plumbing --------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.dsx_last_error(self._ctx)
+            raise DsxError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None:
+            self._lib.dsx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plan ------------------------------------------------------------------------------------
+    def plan(self, height, width, cells_config, no_cells_config, microscope_high_int=2700,
+             max_batch=32, flatfield=None, darkfield=None):  # fmt: skip
+        cells, no_cells = _as_cfg(cells_config), _as_cfg(no_cells_config)
+
+        def call(flat_p, dark_p, dark_h, dark_w):
+            rc = self._lib.dsx_plan(self._ctx, int(height), int(width), int(max_batch), ctypes.byref(cells),
+                                    ctypes.byref(no_cells), float(microscope_high_int), flat_p, dark_p,
+                                    int(dark_h), int(dark_w))  # fmt: skip
+            if rc == -1:  # the reference raises ValueError for these (filtering.py:107-112, 379-391)
+                raise ValueError(self._lib.dsx_last_error(self._ctx).decode())
+            self._check(rc)
+            info = _PlanInfo()
+            self._check(self._lib.dsx_plan_info(self._ctx, ctypes.byref(info)))
+            return info
+
+        if (flatfield is None) != (darkfield is None):
+            raise ValueError("flatfield and darkfield must be given together")
+        info = call(None, None, 0, 0)
+        if flatfield is not None:
+            flat = np.ascontiguousarray(flatfield, dtype=np.float32)
+            dark = np.ascontiguousarray(darkfield, dtype=np.float32)
+            out_shape = (info.out_height, info.out_width)
+            if flat.ndim != 2 or dark.ndim != 2:
+                raise ValueError("flatfield / darkfield must be 2-D planes")
+            # same checks (and messages) as flatfield_correction(), filtering.py:377-391
+            cropped = dark[: out_shape[0], : out_shape[1]].shape
+            if cropped != out_shape:
+                raise ValueError(
+                    "Please, check the shape of the darkfield. "
+                    "Image: {} - Darkfield: {}".format(out_shape, cropped)
+                )
+            if flat.shape != out_shape:
+                raise ValueError(
+                    "Please, check the shape of the flatfield."
+                    "Image: {} - Flatfield: {}".format(out_shape, flat.shape)
+                )
+            info = call(flat.ctypes.data_as(ctypes.c_void_p), dark.ctypes.data_as(ctypes.c_void_p),
+                        dark.shape[0], dark.shape[1])  # fmt: skip
+        self.info = info
+        return info
+
+    @property
+    def out_shape(self):
+        return (self.info.out_height, self.info.out_width)
+
+    @property
+    def levels(self):
+        return self.info.levels
+
+    def level_shape(self, level):
+        return (self.info.level_h[level], self.info.level_w[level])
+
+    # -- run -------------------------------------------------------------------------------------
+    def run(self, planes, out_dtype=np.float32, return_cfg=False):
+        """Host arrays in, host arrays out: ``planes[n, H, W]`` (uint16 / float32)."""
+        a = np.ascontiguousarray(planes)
+        if a.ndim == 2:
+            a = a[None]
+        if a.ndim != 3 or a.shape[1:] != (self.info.height, self.info.width):
+            raise ValueError("planes must be [n, {}, {}]".format(self.info.height, self.info.width))
+        n = a.shape[0]
+        out = np.empty((n,) + self.out_shape, dtype=out_dtype)
+        cfg = np.zeros(n, dtype=np.int32)
+        self._check(
+            self._lib.dsx_run_host(self._ctx, a.ctypes.data_as(ctypes.c_void_p), _dtype_code(a.dtype), n,
+                                   out.ctypes.data_as(ctypes.c_void_p), _dtype_code(out.dtype),
+                                   cfg.ctypes.data_as(ctypes.c_void_p))
+        )  # fmt: skip
+        return (out, cfg) if return_cfg else out
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def run_device(self, d_in, in_dtype, n, d_out, out_dtype, d_cfg=None):
+        """Device buffers; asynchronous on the engine stream."""
+        self._check(
+            self._lib.dsx_run_device(self._ctx, ctypes.c_void_p(d_in.ptr), _dtype_code(in_dtype), int(n),
+                                     ctypes.c_void_p(d_out.ptr), _dtype_code(out_dtype),
+                                     ctypes.c_void_p(d_cfg.ptr) if d_cfg is not None else None)
+        )  # fmt: skip
+
+    def sync(self):
+        self._check(self._lib.dsx_sync(self._ctx))
+
+    def timer_start(self):
+        self._check(self._lib.dsx_timer_start(self._ctx))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        self._check(self._lib.dsx_timer_stop(self._ctx, ctypes.byref(ms)))
+        return ms.value
+
+    def constants_device(self):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self._lib.dsx_constants_device(self._ctx, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def profile(self, on):
+        self._check(self._lib.dsx_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self):
+        ms = (ctypes.c_float * 16)()
+        cnt = (ctypes.c_int32 * 16)()
+        names = (ctypes.c_char_p * 16)()
+        n = ctypes.c_int()
+        self._check(self._lib.dsx_profile_read(self._ctx, 16, ms, cnt, names, ctypes.byref(n)))
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+    # -- parity hooks ----------------------------------------------------------------------------
+    def set_stop_after(self, stage):
+        self._check(self._lib.dsx_set_stop_after(self._ctx, int(stage)))
+
+    def stats(self, plane):
+        f, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
+        self._check(self._lib.dsx_get_stats(self._ctx, int(plane), ctypes.byref(f), ctypes.byref(b), ctypes.byref(c)))
+        return f.value, b.value, c.value
+
+    def thresholds(self, plane, level):
+        o, t = ctypes.c_float(), ctypes.c_float()
+        self._check(self._lib.dsx_get_thresholds(self._ctx, int(plane), int(level), ctypes.byref(o), ctypes.byref(t)))
+        return o.value, t.value
+
+    def level_array(self, plane, level, stage=STAGE_DETAIL):
+        out = np.empty(self.level_shape(level), dtype=np.float32)
+        self._check(self._lib.dsx_get_level(self._ctx, int(plane), int(level), int(stage),
+                                            out.ctypes.data_as(ctypes.c_void_p)))  # fmt: skip
+        return out

@@ -1,0 +1,139 @@
+/*
+ * dsx.h  --  C ABI of the MI355X destripe engine (libdsx_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of AllenNeuralDynamics/aind-smartspim-destripe: the per-plane
+ * stripe filter.  Every entry point below replaces a piece of the reference's Python interface
+ * (file:line relative to /root/reference/code/aind_smartspim_destripe/):
+ *
+ *   dsx_plan()        <- the arguments of filter_stripes()            filtering.py:417-424
+ *                        (cells_config / no_cells_config dicts splatted into
+ *                         log_space_fft_filtering(), filtering.py:139-145, 464, 467;
+ *                         microscope_high_int, filtering.py:423, 462;
+ *                         shadow_correction {flatfield, darkfield}, filtering.py:470-489)
+ *   dsx_run_host()    <- the z-loop over planes of execute_worker()    zarr_destriper.py:319-327
+ *                        and read_filter_save()                        destriper.py:194-200
+ *   dsx_run_device()  <- same, operands already resident in HBM (what bench.py times)
+ *   dsx_get_*()       <- per-level internals for parity tests (Otsu threshold filtering.py:190-193,
+ *                        row medians filtering.py:200-202, cH / filtered cH filtering.py:186,217)
+ *
+ * Plain C types only; no torch / numpy types cross this boundary.  One context per GPU per
+ * process; no global state; every call is synchronous unless stated.  All functions return 0
+ * on success or a negative DSX_E* code; dsx_last_error() gives the message.
+ *
+ * Reference-side binding: see INTEGRATION.md (ctypes stub for filtering.py / zarr_destriper.py).
+ */
+#ifndef DSX_H
+#define DSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSX_VERSION 100
+
+/* error codes */
+#define DSX_OK 0
+#define DSX_EINVAL (-1)   /* bad argument (reference raises ValueError)            */
+#define DSX_ENOPLAN (-2)  /* dsx_run_* before dsx_plan                              */
+#define DSX_EHIP (-3)     /* HIP runtime error                                      */
+#define DSX_ENOMEM (-4)   /* device or host allocation failed                       */
+#define DSX_ELIMIT (-5)   /* plane exceeds an implementation limit                  */
+
+/* plane element types */
+#define DSX_U16 0 /* uint16 pixels (TIFF path, destriper.py:172-200)                 */
+#define DSX_F32 1 /* float32 pixels (Zarr path, zarr_destriper.py:1049)              */
+
+/* wavelet ids (only db3 is used in production, run_capsule.py:374-390) */
+#define DSX_WAVELET_DB3 3
+
+/* stage buffers for dsx_get_level() */
+#define DSX_STAGE_APPROX 0 /* aa_l (before the inverse pass overwrites it with c_l)   */
+#define DSX_STAGE_DETAIL 1 /* da_l == cH_l, or Delta_l once the row filter has run    */
+
+typedef struct dsx_ctx dsx_ctx;
+
+/* One config dict of the reference: {"wavelet","level","sigma","max_threshold"}. */
+typedef struct dsx_cfg {
+  int32_t wavelet;     /* DSX_WAVELET_DB3                                             */
+  int32_t level;       /* -1 == None (maximum level), 0 == filter is the identity + 2 */
+  float sigma;         /* > 0                                                         */
+  float max_threshold; /* upper bound of the Otsu threshold                           */
+} dsx_cfg;
+
+/* Geometry of a planned plane (filled by dsx_plan_info). */
+typedef struct dsx_plan_info_t {
+  int32_t height, width;         /* input plane                                       */
+  int32_t out_height, out_width; /* result plane: H + (H & 1) when any level runs     */
+  int32_t levels;                /* decomposition depth actually run (max of both cfg) */
+  int32_t level_h[16], level_w[16]; /* cH shape per level, index 0 == finest           */
+  int32_t fft_len[16];           /* transform length used by the row filter per level  */
+  int32_t fft_halo[16];          /* periodic halo K (0 == direct length-w transform)   */
+  int32_t max_batch;             /* planes per cohort                                  */
+  uint64_t workspace_bytes;      /* device workspace                                   */
+} dsx_plan_info_t;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int dsx_init(int device, dsx_ctx** out_ctx);
+void dsx_destroy(dsx_ctx* ctx);
+const char* dsx_last_error(const dsx_ctx* ctx); /* ctx may be NULL: last dsx_init error */
+int dsx_device_count(void);
+
+/* ---- plan: everything filter_stripes() takes besides the plane itself --------------------- */
+/* flat / dark: host float32 planes (flat[H*W] row-major, dark[dark_h*dark_w] row-major, cropped
+ * to the plane as flatfield_correction() does, filtering.py:377) or NULL for no shading.      */
+int dsx_plan(dsx_ctx* ctx, int height, int width, int max_batch, const dsx_cfg* cells_config,
+             const dsx_cfg* no_cells_config, double microscope_high_int, const float* flat,
+             const float* dark, int dark_h, int dark_w);
+int dsx_plan_info(const dsx_ctx* ctx, dsx_plan_info_t* info);
+/* Same, with the shading planes already in device memory (e.g. after an RCCL broadcast). */
+int dsx_set_shading_device(dsx_ctx* ctx, const float* d_flat, const float* d_dark, int dark_h,
+                           int dark_w);
+/* Device address + size of the constant blob (twiddles, gain tables, shading) so that a host
+ * program can broadcast it between ranks (RCCL) instead of rebuilding it per rank.              */
+int dsx_constants_device(const dsx_ctx* ctx, void** d_ptr, size_t* bytes);
+
+/* ---- run ---------------------------------------------------------------------------------- */
+/* n planes, C-order [n, H, W] in, [n, H', W'] out.  out_dtype DSX_F32: exp(y)+1 (after shading
+ * if planned, before the integer cast); DSX_U16: clip to [0, 65535] and truncate.
+ * cfg_used (nullable): per plane 1 == cells_config, 0 == no_cells_config.                     */
+int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, int out_dtype,
+                 int32_t* cfg_used);
+/* Device pointers; asynchronous on the context stream (call dsx_sync).  d_cfg_used nullable. */
+int dsx_run_device(dsx_ctx* ctx, const void* d_in, int in_dtype, int n, void* d_out,
+                   int out_dtype, int32_t* d_cfg_used);
+int dsx_sync(dsx_ctx* ctx);
+
+/* ---- device memory + timing helpers for host programs without a GPU array library --------- */
+int dsx_malloc(dsx_ctx* ctx, size_t bytes, void** d_ptr);
+int dsx_free(dsx_ctx* ctx, void* d_ptr);
+int dsx_memcpy_h2d(dsx_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int dsx_memcpy_d2h(dsx_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+int dsx_memcpy_d2d(dsx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+/* HIP events on the context stream: start, stop -> elapsed milliseconds. */
+int dsx_timer_start(dsx_ctx* ctx);
+int dsx_timer_stop(dsx_ctx* ctx, float* ms);
+/* Per-kernel-class device time of the runs since the last reset (HIP events around every
+ * launch; slows the pipeline down, for diagnosis only).  names: NUL-separated list.           */
+int dsx_profile_enable(dsx_ctx* ctx, int on);
+int dsx_profile_read(dsx_ctx* ctx, int max_classes, float* ms, int32_t* launches,
+                     const char** names, int* n_classes);
+
+/* ---- parity / debug hooks (state of the LAST cohort of the last run) ----------------------- */
+/* Per plane of the last cohort: fore/back means and chosen config (filtering.py:459-462). */
+int dsx_get_stats(dsx_ctx* ctx, int plane, double* fore_mean, double* back_mean,
+                  int32_t* cfg_used);
+/* Per plane and level (0 == finest): Otsu value (of cH^2) and the threshold actually used. */
+int dsx_get_thresholds(dsx_ctx* ctx, int plane, int level, float* otsu, float* threshold);
+/* Copy a level buffer [h, w] (float32, dense) of a plane to the host. */
+int dsx_get_level(dsx_ctx* ctx, int plane, int level, int stage, float* out);
+/* Stop the pipeline after a stage (0 == run everything, 1 == after the forward transform +
+ * thresholds, 2 == after the row filter) so that dsx_get_level can read cH / Delta.           */
+int dsx_set_stop_after(dsx_ctx* ctx, int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSX_H */

@@ -1,0 +1,183 @@
+// Host-side (g++) checks of the code the HIP kernels share with the CPU:
+//   fft  <M>                     Stockham passes built from dsx_fft_core.h vs a naive DFT
+//   rows <H> <W> <sigma> <level> <lvl>  emulates k_rowfilter's spectral pipeline for one level with the
+//                                planned (M, K, radices, G tables) and compares with the exact
+//                                length-w circular operator of the reference (packed-index gains)
+//   plan <H> <W> <s0> <l0> <s1> <l1>    prints the plan (levels, dims, M, K, radices)
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <complex>
+#include <vector>
+
+#include "../../aind_smartspim_destripe_amd/csrc/dsx_fft_core.h"
+#include "../../aind_smartspim_destripe_amd/csrc/dsx_plan.h"
+
+typedef std::complex<double> cd;
+
+static void run_passes(std::vector<dsx_c32>& buf, const std::vector<dsx_c32>& tw, const int* radix, int npass) {
+  const int M = (int)buf.size();
+  int s = 1;
+  for (int pi = 0; pi < npass; ++pi) {
+    const int R = radix[pi];
+    const float inv_s = 1.0f / (float)s;
+    const int nb = M / R;
+    if (R == 2 || R == 3 || R == 4 || R == 5) {
+      // read phase for every butterfly, then compute + scatter phase (what a wave does)
+      std::vector<dsx_c32> regs((size_t)nb * R);
+      for (int b = 0; b < nb; ++b) {
+        switch (R) {
+          case 2: dsx_bfly_load<2>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 3: dsx_bfly_load<3>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 4: dsx_bfly_load<4>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 5: dsx_bfly_load<5>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+        }
+      }
+      for (int b = 0; b < nb; ++b) {
+        switch (R) {
+          case 2: dsx_bfly_store<2>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
+          case 3: dsx_bfly_store<3>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
+          case 4: dsx_bfly_store<4>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
+          case 5: dsx_bfly_store<5>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
+        }
+      }
+    } else {
+      std::vector<dsx_c32> acc(M);
+      for (int o = 0; o < M; ++o) acc[o] = dsx_generic_output(buf.data(), tw.data(), o, M, s, inv_s, R);
+      buf = acc;
+    }
+    s *= R;
+  }
+}
+
+static std::vector<dsx_c32> twiddles(int M) {
+  std::vector<dsx_c32> tw(M);
+  for (int t = 0; t < M; ++t) {
+    const double a = -2.0 * M_PI * t / M;
+    tw[t] = dsx_mk((float)cos(a), (float)sin(a));
+  }
+  return tw;
+}
+
+static int cmd_fft(int M) {
+  std::vector<int> rad = dsx::factorize(M);
+  std::vector<dsx_c32> buf(M);
+  std::vector<cd> x(M);
+  srand(M);
+  for (int i = 0; i < M; ++i) {
+    x[i] = cd(rand() / (double)RAND_MAX - 0.5, rand() / (double)RAND_MAX - 0.5);
+    buf[i] = dsx_mk((float)x[i].real(), (float)x[i].imag());
+  }
+  run_passes(buf, twiddles(M), rad.data(), (int)rad.size());
+  double err = 0, nrm = 0;
+  for (int k = 0; k < M; ++k) {
+    cd acc = 0;
+    for (int j = 0; j < M; ++j) acc += x[j] * std::polar(1.0, -2.0 * M_PI * (double)((long long)j * k % M) / M);
+    err = fmax(err, std::abs(acc - cd(buf[k].x, buf[k].y)));
+    nrm = fmax(nrm, std::abs(acc));
+  }
+  printf("{\"M\": %d, \"npass\": %d, \"rel_err\": %.3e}\n", M, (int)rad.size(), err / nrm);
+  return 0;
+}
+
+static int cmd_plan(int H, int W, double s0, int l0, double s1, int l1, dsx::Plan& p, bool print) {
+  dsx::HostCfg cfg[2] = {{l0, s0, 12.0}, {l1, s1, 3.0}};
+  std::string e = dsx::build_plan(H, W, cfg, p);
+  if (!e.empty()) {
+    printf("{\"error\": \"%s\"}\n", e.c_str());
+    return 1;
+  }
+  if (!print) return 0;
+  printf("{\"H\": %d, \"W\": %d, \"Hout\": %d, \"Wout\": %d, \"L\": %d, \"plane_floats\": %lld, \"levels\": [", p.H, p.W,
+         p.Hout, p.Wout, p.L, p.plane_floats);
+  for (int l = 0; l < p.L; ++l) {
+    const dsx::LevelPlan& lp = p.lv[l];
+    printf("%s{\"h\": %d, \"w\": %d, \"ld\": %d, \"M\": %d, \"K\": %d, \"radix\": [", l ? ", " : "", lp.h, lp.w, lp.ld, lp.M,
+           lp.K);
+    for (int i = 0; i < lp.npass; ++i) printf("%s%d", i ? ", " : "", lp.radix[i]);
+    printf("]}");
+  }
+  printf("]}\n");
+  return 0;
+}
+
+// Emulate the spectral pipeline of k_rowfilter for two random rows at one level and compare with the
+// exact operator  LP(x) = irfft_packed(rfft_packed(x) * e),  e[j] = exp(-j^2 / (2 s^2)).
+static int cmd_rows(int H, int W, double sigma, int level, int lvl) {
+  dsx::Plan p;
+  if (cmd_plan(H, W, sigma, level, sigma, level, p, false)) return 1;
+  if (lvl >= p.L) { printf("{\"error\": \"level out of range\"}\n"); return 1; }
+  const dsx::LevelPlan& lp = p.lv[lvl];
+  const int N = lp.w, M = lp.M, K = lp.K;
+  const double s = lp.h * (sigma / (double)std::min(H, W));
+  std::vector<double> xa(N), xb(N);
+  srand(N * 7 + lvl);
+  for (int n = 0; n < N; ++n) {
+    xa[n] = rand() / (double)RAND_MAX - 0.3;
+    xb[n] = rand() / (double)RAND_MAX - 0.6;
+  }
+  // exact reference operator in double: Y[k] = ep X[k] + em X[N-k]
+  std::vector<double> ep, em;
+  dsx::packed_gains(N, s, ep, em);
+  auto exact = [&](const std::vector<double>& x) {
+    std::vector<cd> X(N), Y(N);
+    for (int k = 0; k < N; ++k) {
+      cd acc = 0;
+      for (int j = 0; j < N; ++j) acc += x[j] * std::polar(1.0, -2.0 * M_PI * (double)((long long)j * k % N) / N);
+      X[k] = acc;
+    }
+    for (int k = 0; k < N; ++k) Y[k] = ep[k] * X[k] + em[k] * X[(N - k) % N];
+    std::vector<double> y(N);
+    for (int n = 0; n < N; ++n) {
+      cd acc = 0;
+      for (int k = 0; k < N; ++k) acc += Y[k] * std::polar(1.0, 2.0 * M_PI * (double)((long long)n * k % N) / N);
+      y[n] = acc.real() / N;
+    }
+    return y;
+  };
+  std::vector<double> ya = exact(xa), yb = exact(xb);
+  // kernel pipeline in float
+  std::vector<dsx_c32> buf(M, dsx_mk(0.f, 0.f));
+  for (int n = 0; n < N; ++n) {
+    dsx_c32 z = dsx_mk((float)xa[n], (float)xb[n]);
+    buf[K + n] = z;
+    if (K > 0) {
+      if (n <= K) buf[K + N + n] = z;
+      if (n >= N - K) buf[n - (N - K)] = z;
+    }
+  }
+  std::vector<dsx_c32> tw(M);
+  for (int t = 0; t < M; ++t) tw[t] = dsx_mk(p.consts[lp.tw_off + t].re, p.consts[lp.tw_off + t].im);
+  run_passes(buf, tw, lp.radix, lp.npass);
+  const dsx::C32* g1 = &p.consts[lp.g_off[1]];
+  const dsx::C32* g2 = g1 + M;
+  std::vector<dsx_c32> v(M);
+  for (int k = 0; k < M; ++k) {
+    dsx_c32 u = buf[k], ur = buf[k == 0 ? 0 : M - k];
+    dsx_c32 r = dsx_add(dsx_mul(dsx_mk(g1[k].re, g1[k].im), u), dsx_mul(dsx_mk(g2[k].re, g2[k].im), ur));
+    v[k] = dsx_mk(r.y, r.x);
+  }
+  run_passes(v, tw, lp.radix, lp.npass);
+  double err = 0, nrm = 0;
+  for (int n = 0; n < N; ++n) {
+    const double la = v[K + n].y / M, lb = v[K + n].x / M;
+    err = fmax(err, fmax(fabs(la - ya[n]), fabs(lb - yb[n])));
+    nrm = fmax(nrm, fmax(fabs(ya[n]), fabs(yb[n])));
+  }
+  printf("{\"N\": %d, \"M\": %d, \"K\": %d, \"rel_err\": %.3e}\n", N, M, K, err / nrm);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 3 && !strcmp(argv[1], "fft")) return cmd_fft(atoi(argv[2]));
+  if (argc >= 8 && !strcmp(argv[1], "plan")) {
+    dsx::Plan p;
+    return cmd_plan(atoi(argv[2]), atoi(argv[3]), atof(argv[4]), atoi(argv[5]), atof(argv[6]), atoi(argv[7]), p, true);
+  }
+  if (argc >= 7 && !strcmp(argv[1], "rows"))
+    return cmd_rows(atoi(argv[2]), atoi(argv[3]), atof(argv[4]), atoi(argv[5]), atoi(argv[6]));
+  fprintf(stderr, "usage: fft M | plan H W s0 l0 s1 l1 | rows H W sigma level lvl\n");
+  return 2;
+}
