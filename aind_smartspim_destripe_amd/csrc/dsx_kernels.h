@@ -359,6 +359,10 @@ __global__ __launch_bounds__(64) void k_otsu(OtsuArgs a) {
   const long long pl = (long long)plane * a.L + lvl;
   const unsigned* mm = a.minmax + pl * 2;
   const float q_lo = as_f32(~mm[0]), q_hi = as_f32(mm[1]);
+  // The class statistics are accumulated sequentially in numpy's order (cumsum forward for
+  // class 1, cumsum over the reversed arrays for class 2): empty bins then give bit-identical
+  // variances on both sides, and "first maximum" picks the same bin as np.argmax.
+  __shared__ double s_cnt[256], s_cb[256], s_w1[256], s_m1[256];
   double otsu;
   if (!(q_lo < q_hi)) {
     otsu = (double)q_lo;  // all values equal: threshold_otsu returns that value
@@ -366,51 +370,33 @@ __global__ __launch_bounds__(64) void k_otsu(OtsuArgs a) {
     const double first = (double)q_lo, last = (double)q_hi;
     const double step = (last - first) / 256.0;
     const unsigned* h = a.hist + pl * 256;
-    double cnt[4], cb[4], bc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int g = 4 * lane + i;
+      const int g = lane + 64 * i;
       const double e0 = first + g * step;
       const double e1 = (g == 255) ? last : first + (g + 1) * step;
-      bc[i] = 0.5 * (e0 + e1);
-      cnt[i] = (double)h[g];
-      cb[i] = cnt[i] * bc[i];
+      const double c = (double)h[g];
+      s_cnt[g] = c;
+      s_cb[g] = c * (0.5 * (e0 + e1));
     }
-    const double lw = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-    const double ls = cb[0] + cb[1] + cb[2] + cb[3];
-    double w_inc = lw, s_inc = ls, r_inc = ls;  // inclusive scans: forward counts, forward cb, reverse cb
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const double tw_ = __shfl_up(w_inc, o);
-      const double ts_ = __shfl_up(s_inc, o);
-      const double tr_ = __shfl_down(r_inc, o);
-      if (lane >= o) { w_inc += tw_; s_inc += ts_; }
-      if (lane + o < 64) r_inc += tr_;
-    }
-    const double total_w = __shfl(w_inc, 63);
-    double w1 = w_inc - lw, s1 = s_inc - ls;  // exclusive prefixes
-    double s2 = r_inc;                         // sum of cb over bins >= 4 * lane
-    double best = -1.0;
+    __syncthreads();
     int best_g = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int g = 4 * lane + i;
-      w1 += cnt[i];
-      s1 += cb[i];
-      s2 -= cb[i];  // now: sum over bins > g
-      if (g < 255) {
-        const double w2 = total_w - w1;
-        const double m1 = s1 / w1, m2 = s2 / w2;
-        const double d = m1 - m2;
-        const double var = w1 * w2 * d * d;
-        if (var > best) { best = var; best_g = g; }
+    if (lane == 0) {
+      double w = 0.0, sacc = 0.0;
+      for (int g = 0; g < 256; ++g) {
+        w += s_cnt[g];
+        sacc += s_cb[g];
+        s_w1[g] = w;
+        s_m1[g] = sacc / w;
       }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ob = __shfl_xor(best, o);
-      const int og = __shfl_xor(best_g, o);
-      if (ob > best || (ob == best && og < best_g)) { best = ob; best_g = og; }
+      double w2 = 0.0, s2 = 0.0, best = -1.0;
+      for (int g = 255; g >= 1; --g) {
+        w2 += s_cnt[g];
+        s2 += s_cb[g];
+        const double d = s_m1[g - 1] - s2 / w2;
+        const double var = (s_w1[g - 1] * w2) * (d * d);  // variance12[g - 1]
+        if (var >= best) { best = var; best_g = g - 1; }  // descending scan: ties keep the lower bin
+      }
     }
     const double e0 = first + best_g * step;
     const double e1 = (best_g == 255) ? last : first + (best_g + 1) * step;
