@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 2048 x 2048 uint16 slices/s destriped + achieved HBM GB/s (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (filter_stripes semantics, production parameters,
+uint16 in -> uint16 out) over a batch of 256 synthetic striped 2048 x 2048 slices that is already
+resident in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU; slices shard
+embarrassingly (weak scaling, 256 slices per rank), the only collective is an RCCL broadcast of the
+filter-constant blob before the timed region.  torch is used here for the process group only
+(barrier, max-reduce of the time, that broadcast); the engine itself is the C-ABI HIP library.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from aind_smartspim_destripe_amd import engine as eng_mod  # noqa: E402
+from aind_smartspim_destripe_amd import synth  # noqa: E402
+
+H = W = 2048
+ALGO_BYTES_PER_SLICE = H * W * 2 * 2  # compulsory traffic: uint16 read + uint16 write
+HBM_PEAK_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def init_dist(n_gpus):
+    """Process group for N > 1 (RCCL for device tensors, gloo for host tensors)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return None, 0, 1, 0
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local)
+    try:
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+    except Exception as e:  # pragma: no cover - environment dependent
+        log("[bench] mixed backend init failed ({}); falling back to nccl".format(e))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    return dist, rank, world, local
+
+
+def broadcast_constants(dist, engine, rank):
+    """RCCL broadcast (root 0) of the filter-constant blob: twiddles + per-level gain tables."""
+    import ctypes
+
+    import torch
+
+    ptr, nbytes = engine.constants_device()
+    buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    lib, ctx = engine._lib, engine._ctx
+    if rank == 0:
+        lib.dsx_memcpy_d2d(ctx, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(ptr), nbytes)
+        engine.sync()
+    dist.broadcast(buf, src=0)
+    torch.cuda.synchronize()
+    if rank != 0:
+        lib.dsx_memcpy_d2d(ctx, ctypes.c_void_p(ptr), ctypes.c_void_p(buf.data_ptr()), nbytes)
+        engine.sync()
+    return nbytes
+
+
+def cpu_baseline(n_planes):
+    """The NumPy oracle (a port of the reference algorithm) on one host core, bounded sample."""
+    from oracle import destripe_oracle as orc
+
+    planes = synth.synthetic_bank(n_planes, H, W)
+    orc.filter_stripes(planes[0][:256, :256].copy(), "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
+                       synth.ZARR_PATH_HIGH_INT)  # fmt: skip  (warm numpy)
+    t0 = time.perf_counter()
+    for k in range(n_planes):
+        out = orc.filter_stripes(planes[k], "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
+                                 synth.ZARR_PATH_HIGH_INT)  # fmt: skip
+        np.clip(out, 0, 65535).astype(np.uint16)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(n_planes / dt, 4),
+        "unit": "slices/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "{} synthetic 2048x2048 uint16 planes (bank planes 0..{}), NumPy oracle filter_stripes + uint16 "
+                  "cast, one process, OMP_NUM_THREADS=1, {:.1f} s".format(n_planes, n_planes - 1, dt),
+    }  # fmt: skip
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="slices per step per GPU")
+    ap.add_argument("--cohort", type=int, default=int(os.environ.get("DSX_COHORT", "256")),
+                    help="planes per launch chain (workspace size)")  # fmt: skip
+    ap.add_argument("--cpu-planes", type=int, default=16, help="planes of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--kernel-breakdown", action="store_true", help="one extra untimed step with per-kernel events")
+    args = ap.parse_args()
+
+    dist, rank, world, local = init_dist(args.gpus)
+    if world != args.gpus:
+        log("[bench] WORLD_SIZE {} != --gpus {}; using WORLD_SIZE".format(world, args.gpus))
+
+    engine = eng_mod.DestripeEngine(local)
+    info = engine.plan(H, W, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT,
+                       max_batch=min(args.cohort, args.batch))  # fmt: skip
+    blob_bytes = 0
+    if dist is not None:
+        blob_bytes = broadcast_constants(dist, engine, rank)
+
+    # synthetic stack: 32 unique planes, slice z = bank[z % 32] rolled by z // 32 rows
+    t0 = time.perf_counter()
+    bank = synth.synthetic_bank(min(32, args.batch), H, W)
+    stack = synth.synthetic_stack(args.batch, H, W, bank=bank)
+    log("[bench] rank {} synthetic stack {} in {:.1f} s".format(rank, stack.shape, time.perf_counter() - t0))
+    d_in = engine.alloc(stack.nbytes)
+    d_out = engine.alloc(stack.nbytes)
+    d_cfg = engine.alloc(4 * args.batch)
+    d_in.upload(stack)
+
+    def step():
+        engine.run_device(d_in, np.uint16, args.batch, d_out, np.uint16, d_cfg)
+
+    def barrier():
+        engine.sync()
+        if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t_start = time.perf_counter()
+    engine.timer_start()
+    for _ in range(args.steps):
+        step()
+    dev_ms = engine.timer_stop()  # HIP events on the engine stream; also synchronises it
+    barrier()
+    wall = time.perf_counter() - t_start
+
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(t[0]), float(t[1])
+
+    # sanity on the result of the last step: config branch per plane and a checksum
+    cfg = d_cfg.download((args.batch,), np.int32)
+    out_head = d_out.download((1, H, W), np.uint16)
+    n_cells = int(cfg.sum())
+
+    breakdown = None
+    if args.kernel_breakdown and rank == 0:
+        engine.profile(True)
+        step()
+        engine.sync()
+        breakdown = {k: {"ms": round(v[0], 4), "launches": v[1]} for k, v in engine.profile_read().items()}
+        engine.profile(False)
+
+    if rank == 0:
+        slices = args.batch * world * args.steps
+        value = slices / wall
+        ms_per_step = 1e3 * wall / args.steps
+        dev_ms_per_step = dev_ms / args.steps
+        achieved = args.batch * ALGO_BYTES_PER_SLICE / (dev_ms_per_step * 1e-3) / 1e9
+        result = {
+            "metric": "2048x2048 uint16 slices/s destriped",
+            "value": round(value, 2),
+            "unit": "slices/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "batch of {} x 2048x2048 uint16 slices per GPU, log-space wavelet-FFT destripe "
+                            "(filter_stripes semantics, production cells/no-cells configs, high_int 2500), "
+                            "uint16 out, inputs resident in HBM".format(args.batch),
+                "slices_per_gpu": args.batch,
+                "cohort": min(args.cohort, args.batch),
+                "levels": info.levels,
+                "fft_len": [info.fft_len[i] for i in range(info.levels)],
+                "planes_with_cells_config": n_cells,
+                "parallelism": "z-sharded x{}".format(world),
+                "constants_broadcast_bytes": blob_bytes,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "destripe launch chain (k_dwt_fwd, k_hist, k_otsu, k_rowfilter, k_idwt) over one batch",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": args.batch * ALGO_BYTES_PER_SLICE,
+                "device_ms_per_launch": round(dev_ms_per_step, 4),
+                "read_only_frac": round(achieved / 2 / HBM_PEAK_GBS, 5),
+            },
+            "out_checksum": int(out_head.astype(np.uint64).sum()),
+        }
+        if breakdown is not None:
+            result["kernel_ms"] = breakdown
+        if world == 1 and args.cpu_planes > 0:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_planes)
+        print(json.dumps(result), flush=True)
+
+    d_in.free()
+    d_out.free()
+    d_cfg.free()
+    engine.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
