@@ -121,6 +121,118 @@ struct dsx_bfly<5> {
   }
 };
 
+// ---- odd-prime register butterflies (P = 7, 11, 13, 17, 19): symmetric form, (P-1)^2 real FMAs -----
+// X[k], X[P-k] = A -/+ iB,  A = x0 + sum_j cos(2 pi jk/P) (x_j + x_{P-j}),  B = sum_j sin(2 pi jk/P) (x_j - x_{P-j})
+DSX_HD constexpr float dsx_root_cos(int P, int j) {
+  switch (P) {
+    case 7: {
+      constexpr float t[7] = {1.0f, 0.62348980185873359f, -0.22252093395631434f, -0.90096886790241903f, -0.90096886790241915f, -0.22252093395631459f, 0.62348980185873337f};
+      return t[j];
+    }
+    case 11: {
+      constexpr float t[11] = {1.0f, 0.84125353283118121f, 0.41541501300188644f, -0.142314838273285f, -0.65486073394528499f, -0.95949297361449737f, -0.95949297361449748f, -0.65486073394528521f, -0.14231483827328523f, 0.41541501300188605f, 0.84125353283118121f};
+      return t[j];
+    }
+    case 13: {
+      constexpr float t[13] = {1.0f, 0.88545602565320991f, 0.56806474673115592f, 0.12053668025532301f, -0.35460488704253545f, -0.74851074817110119f, -0.97094181742605201f, -0.97094181742605212f, -0.7485107481711013f, -0.3546048870425359f, 0.1205366802553232f, 0.56806474673115481f, 0.88545602565321002f};
+      return t[j];
+    }
+    case 17: {
+      constexpr float t[17] = {1.0f, 0.93247222940435581f, 0.73900891722065909f, 0.44573835577653831f, 0.092268359463302016f, -0.27366299007208289f, -0.60263463637925629f, -0.85021713572961399f, -0.98297309968390179f, -0.98297309968390179f, -0.8502171357296141f, -0.60263463637925718f, -0.27366299007208311f, 0.092268359463302432f, 0.4457383557765377f, 0.73900891722065853f, 0.93247222940435581f};
+      return t[j];
+    }
+    case 19: {
+      constexpr float t[19] = {1.0f, 0.94581724170063464f, 0.78914050939639357f, 0.54694815812242692f, 0.24548548714079924f, -0.082579345472332269f, -0.40169542465296942f, -0.67728157162574087f, -0.87947375120648896f, -0.98636130340272232f, -0.98636130340272243f, -0.8794737512064893f, -0.6772815716257411f, -0.40169542465296904f, -0.082579345472332741f, 0.24548548714079879f, 0.54694815812242659f, 0.78914050939639391f, 0.94581724170063464f};
+      return t[j];
+    }
+    default: return 0.f;
+  }
+}
+DSX_HD constexpr float dsx_root_sin(int P, int j) {
+  switch (P) {
+    case 7: {
+      constexpr float t[7] = {0.0f, 0.7818314824680298f, 0.97492791218182362f, 0.43388373911755823f, -0.43388373911755801f, -0.97492791218182362f, -0.78183148246802991f};
+      return t[j];
+    }
+    case 11: {
+      constexpr float t[11] = {0.0f, 0.54064081745559756f, 0.90963199535451833f, 0.9898214418809328f, 0.75574957435425827f, 0.28173255684142967f, -0.28173255684142939f, -0.75574957435425816f, -0.98982144188093268f, -0.90963199535451855f, -0.54064081745559744f};
+      return t[j];
+    }
+    case 13: {
+      constexpr float t[13] = {0.0f, 0.46472317204376851f, 0.82298386589365635f, 0.99270887409805397f, 0.93501624268541483f, 0.66312265824079519f, 0.23931566428755768f, -0.23931566428755743f, -0.66312265824079497f, -0.93501624268541472f, -0.99270887409805397f, -0.82298386589365702f, -0.4647231720437684f};
+      return t[j];
+    }
+    case 17: {
+      constexpr float t[17] = {0.0f, 0.36124166618715292f, 0.67369564364655721f, 0.89516329135506234f, 0.99573417629503447f, 0.96182564317281904f, 0.7980172272802396f, 0.52643216287735606f, 0.18374951781657037f, -0.18374951781657012f, -0.52643216287735584f, -0.79801722728023894f, -0.96182564317281904f, -0.99573417629503447f, -0.89516329135506256f, -0.67369564364655776f, -0.36124166618715303f};
+      return t[j];
+    }
+    case 19: {
+      constexpr float t[19] = {0.0f, 0.32469946920468346f, 0.61421271268966782f, 0.83716647826252855f, 0.96940026593933037f, 0.99658449300666985f, 0.9157733266550574f, 0.73572391067313181f, 0.47594739303707367f, 0.16459459028073403f, -0.16459459028073378f, -0.47594739303707312f, -0.73572391067313159f, -0.91577332665505762f, -0.99658449300666985f, -0.96940026593933049f, -0.83716647826252877f, -0.61421271268966737f, -0.32469946920468373f};
+      return t[j];
+    }
+    default: return 0.f;
+  }
+}
+
+template <int P>
+DSX_HD void dsx_bfly_odd(dsx_c32* v) {
+  constexpr int HP = (P - 1) / 2;
+  dsx_c32 sp[HP], sm[HP];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int j = 1; j <= HP; ++j) {
+    sp[j - 1] = dsx_add(v[j], v[P - j]);
+    sm[j - 1] = dsx_sub(v[j], v[P - j]);
+  }
+  const dsx_c32 x0 = v[0];
+  dsx_c32 dc = x0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int j = 0; j < HP; ++j) dc = dsx_add(dc, sp[j]);
+  v[0] = dc;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int k = 1; k <= HP; ++k) {
+    float ar = x0.x, ai = x0.y, br = 0.f, bi = 0.f;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 1; j <= HP; ++j) {
+      const float c = dsx_root_cos(P, (j * k) % P);
+      const float s = dsx_root_sin(P, (j * k) % P);
+      ar += c * sp[j - 1].x;
+      ai += c * sp[j - 1].y;
+      br += s * sm[j - 1].x;
+      bi += s * sm[j - 1].y;
+    }
+    v[k] = dsx_mk(ar + bi, ai - br);      // A - iB
+    v[P - k] = dsx_mk(ar - bi, ai + br);  // A + iB
+  }
+}
+template <>
+struct dsx_bfly<7> {
+  DSX_HD static void run(dsx_c32* v) { dsx_bfly_odd<7>(v); }
+};
+template <>
+struct dsx_bfly<11> {
+  DSX_HD static void run(dsx_c32* v) { dsx_bfly_odd<11>(v); }
+};
+template <>
+struct dsx_bfly<13> {
+  DSX_HD static void run(dsx_c32* v) { dsx_bfly_odd<13>(v); }
+};
+template <>
+struct dsx_bfly<17> {
+  DSX_HD static void run(dsx_c32* v) { dsx_bfly_odd<17>(v); }
+};
+template <>
+struct dsx_bfly<19> {
+  DSX_HD static void run(dsx_c32* v) { dsx_bfly_odd<19>(v); }
+};
+
 // ---- per-butterfly pieces of a pass (used verbatim by k_rowfilter and by the host unit test) ----
 template <int R>
 DSX_HD void dsx_bfly_load(const dsx_c32* buf, int b, int nb, dsx_c32* v) {
@@ -134,14 +246,54 @@ DSX_HD void dsx_bfly_load(const dsx_c32* buf, int b, int nb, dsx_c32* v) {
 template <int R>
 DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float inv_s, dsx_c32* v) {
   const int q = (s == 1) ? 0 : dsx_mod_s(b, s, inv_s);
-  dsx_bfly<R>::run(v);
   const int ps = b - q;
   const int dst = R * b - (R - 1) * q;
-  buf[dst] = v[0];
+  if constexpr (R >= 7) {
+    // odd prime: outputs are produced and scattered pair by pair (X[k], X[R-k]) so that only the
+    // R inputs (folded in place into sums / differences) stay live in registers
+    constexpr int HP = (R - 1) / 2;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-  for (int k = 1; k < R; ++k) buf[dst + s * k] = dsx_mul(v[k], tw[ps * k]);
+    for (int j = 1; j <= HP; ++j) {
+      const dsx_c32 x = v[j], y = v[R - j];
+      v[j] = dsx_add(x, y);
+      v[R - j] = dsx_sub(x, y);
+    }
+    const dsx_c32 x0 = v[0];
+    dsx_c32 dc = x0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 1; j <= HP; ++j) dc = dsx_add(dc, v[j]);
+    buf[dst] = dc;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 1; k <= HP; ++k) {
+      float ar = x0.x, ai = x0.y, br = 0.f, bi = 0.f;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (int j = 1; j <= HP; ++j) {
+        const float c = dsx_root_cos(R, (j * k) % R);
+        const float sn = dsx_root_sin(R, (j * k) % R);
+        ar += c * v[j].x;
+        ai += c * v[j].y;
+        br += sn * v[R - j].x;
+        bi += sn * v[R - j].y;
+      }
+      buf[dst + s * k] = dsx_mul(dsx_mk(ar + bi, ai - br), tw[ps * k]);                  // A - iB
+      buf[dst + s * (R - k)] = dsx_mul(dsx_mk(ar - bi, ai + br), tw[ps * (R - k)]);      // A + iB
+    }
+  } else {
+    dsx_bfly<R>::run(v);
+    buf[dst] = v[0];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 1; k < R; ++k) buf[dst + s * k] = dsx_mul(v[k], tw[ps * k]);
+  }
 }
 
 // one output element o of a generic radix-R pass (any R dividing M / s)

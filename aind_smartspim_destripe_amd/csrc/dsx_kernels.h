@@ -454,6 +454,9 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int M, i
   for (int i = 0; i < MAXB; ++i) {
     const int b = lane + kWave * i;
     if (b < nb) dsx_bfly_store<R>(buf, tw, b, s, inv_s, v[i]);
+    // keep the unrolled butterflies from being interleaved: their temporaries would all be live
+    // at once (215+ VGPRs at 18 values per lane) for no gain -- other waves hide the latency
+    __builtin_amdgcn_sched_barrier(0);
   }
   wave_sync();
 }
@@ -478,25 +481,82 @@ __device__ __forceinline__ void fft_pass_generic(float2* buf, const float2* tw, 
 }
 
 template <int CPL>
-__device__ __forceinline__ void fft_run(float2* buf, const float2* tw, const RowArgs& a, int lane) {
+__device__ __forceinline__ void fft_run(float2* buf, const float2* tw, const RowArgs& a, int lane_in) {
   int s = 1;
   for (int pi = 0; pi < a.npass; ++pi) {
     const int R = a.radix[pi];
     const float inv_s = 1.0f / (float)s;
+    // Opaque copies per iteration: otherwise LICM hoists every case's per-lane address arithmetic
+    // out of this loop and keeps it live across all passes (+25 VGPRs per radix case).
+    int lane = lane_in, M = a.M;
+    asm volatile("" : "+v"(lane), "+s"(M));
     switch (R) {
-      case 2: fft_pass<2, CPL>(buf, tw, a.M, s, inv_s, lane); break;
-      case 3: fft_pass<3, CPL>(buf, tw, a.M, s, inv_s, lane); break;
-      case 4: fft_pass<4, CPL>(buf, tw, a.M, s, inv_s, lane); break;
-      case 5: fft_pass<5, CPL>(buf, tw, a.M, s, inv_s, lane); break;
-      default: fft_pass_generic<CPL>(buf, tw, a.M, s, inv_s, R, lane); break;
+      case 2: fft_pass<2, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 3: fft_pass<3, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 4: fft_pass<4, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 5: fft_pass<5, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 7: fft_pass<7, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 11: fft_pass<11, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 13: fft_pass<13, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 17: fft_pass<17, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 19: fft_pass<19, CPL>(buf, tw, M, s, inv_s, lane); break;
+      default: fft_pass_generic<CPL>(buf, tw, M, s, inv_s, R, lane); break;
     }
     s *= R;
   }
 }
 
+typedef short dsx_s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ dsx_s16x2 as_s16x2(unsigned u) {
+  union { unsigned u; dsx_s16x2 v; } c;
+  c.u = u;
+  return c.v;
+}
+__device__ __forceinline__ unsigned as_u32(dsx_s16x2 v) {
+  union { unsigned u; dsx_s16x2 v; } c;
+  c.v = v;
+  return c.u;
+}
+
+// Per-lane count of packed 16-bit values below a packed threshold, both halves at once:
+// x and t are in signed order (value ^ 0x8000); returns {#(x.lo < t.lo), #(x.hi < t.hi)} packed.
+template <int E>
+__device__ __forceinline__ unsigned count_below_pk16(const unsigned (&x)[E], unsigned t) {
+  const dsx_s16x2 tv = as_s16x2(t);
+  dsx_s16x2 acc = as_s16x2(0u);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const dsx_s16x2 d = __builtin_elementwise_sub_sat(as_s16x2(x[e]), tv);  // < 0  <=>  x < t
+    acc -= (d >> 15);                                                       // -1 per hit
+  }
+  return as_u32(acc);
+}
+
+// largest 16-bit T (per half) with #{x < T} <= rank (per half); x in signed order
+template <int E>
+__device__ __forceinline__ unsigned bisect_pk16(const unsigned (&x)[E], unsigned rank_a, unsigned rank_b) {
+  unsigned ra = 0, rb = 0;
+  for (int bit = 15; bit >= 0; --bit) {
+    const unsigned ta = ra | (1u << bit), tb = rb | (1u << bit);
+    unsigned c = count_below_pk16<E>(x, (ta | (tb << 16)) ^ 0x80008000u);
+    c = __reduce_add_sync(~0ull, c);
+    if ((c & 0xFFFFu) <= rank_a) ra = ta;
+    if ((c >> 16) <= rank_b) rb = tb;
+  }
+  return ra | (rb << 16);
+}
+
+// Register budget per instantiation (second __launch_bounds__ argument = waves per SIMD): the LDS
+// footprint (5 M complex per block) admits that many blocks per CU anyway.
+template <int CPL>
+constexpr int row_waves_per_simd() {
+  return CPL <= 10 ? 4 : (CPL <= 18 ? 3 : 1);
+}
+
 // One wave per pair of rows.  CPL = complex values per lane = ceil(M / 64).
 template <int CPL>
-__global__ __launch_bounds__(256) void k_rowfilter(RowArgs a) {
+__global__ __launch_bounds__(256, row_waves_per_simd<CPL>()) void k_rowfilter(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.M, N = a.w, K = a.K;
@@ -524,55 +584,64 @@ __global__ __launch_bounds__(256) void k_rowfilter(RowArgs a) {
   }
   const float thr = a.thr[(long long)plane * a.L + a.lvl];
 
+  // ---- load both rows; background = masked entries zeroed (filtering.py:195-197) -------------
+  // Order-preserving 32-bit keys, split into packed 16-bit halves {row a | row b << 16}:
+  // hs = high halves, ls = low halves, both in signed order (^ 0x8000) for the saturating compare.
   constexpr int E = CPL;
-  unsigned ka[E], kb[E];
+  unsigned hs[E], ls[E];
   unsigned long long maska = 0, maskb = 0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int n = lane + kWave * e;
-    ka[e] = 0xFFFFFFFFu;
-    kb[e] = 0xFFFFFFFFu;
+    unsigned ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;  // padding sorts last
     if (n < N) {
       const float va = rowa[n];
       const float vb = has_b ? rowb[n] : 0.f;
       const bool ma = fabsf(va) > thr, mb = fabsf(vb) > thr;
       if (ma) maska |= (1ull << e);
       if (mb) maskb |= (1ull << e);
-      ka[e] = f32_key(ma ? 0.f : va);  // background: masked entries are zeroed (filtering.py:197)
-      kb[e] = f32_key(mb ? 0.f : vb);
+      ka = f32_key(ma ? 0.f : va);
+      kb = f32_key(mb ? 0.f : vb);
     }
+    hs[e] = ((ka >> 16) | (kb & 0xFFFF0000u)) ^ 0x80008000u;
+    ls[e] = ((ka & 0xFFFFu) | (kb << 16)) ^ 0x80008000u;
   }
 
-  // exact row medians (np.median, filtering.py:201): k-th smallest by bitwise bisection on keys
+  // ---- exact row medians (np.median, filtering.py:201) ------------------------------------------
+  // k-th smallest key by bisection, 16 bits at a time: first the high half over all elements, then
+  // the low half over the elements that share the selected high half.
   const unsigned k1 = (unsigned)(N - 1) >> 1;
-  unsigned ra = 0, rb = 0;
-  for (int bit = 31; bit >= 0; --bit) {
-    const unsigned ta = ra | (1u << bit), tb = rb | (1u << bit);
-    unsigned c = 0;
+  const unsigned rhi = bisect_pk16<E>(hs, k1, k1);
+  unsigned below = __reduce_add_sync(~0ull, count_below_pk16<E>(hs, rhi ^ 0x80008000u));
+  unsigned lsel[E];
+  {
+    const dsx_s16x2 rv = as_s16x2(rhi ^ 0x80008000u);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      c += (ka[e] < ta) ? 1u : 0u;
-      c += (kb[e] < tb) ? 0x10000u : 0u;
+      const dsx_s16x2 eq = (as_s16x2(hs[e]) == rv);       // -1 where the high half matches
+      lsel[e] = (ls[e] & as_u32(eq)) | (0x7FFF7FFFu & ~as_u32(eq));  // others: +max (never below)
     }
-    c = __reduce_add_sync(~0ull, c);
-    if ((c & 0xFFFFu) <= k1) ra = ta;
-    if ((c >> 16) <= k1) rb = tb;
   }
-  float meda = key_f32(ra), medb = key_f32(rb);
+  const unsigned rlo = bisect_pk16<E>(lsel, k1 - (below & 0xFFFFu), k1 - (below >> 16));
+  const unsigned keya = ((rhi & 0xFFFFu) << 16) | (rlo & 0xFFFFu);
+  const unsigned keyb = (rhi & 0xFFFF0000u) | (rlo >> 16);
+  float meda = key_f32(keya), medb = key_f32(keyb);
   if ((N & 1) == 0) {
-    // second middle order statistic: the smallest element above the first one unless it is tied.
-    // The cross-lane minimum goes through an LDS atomic (once per row pair): shuffle-based
-    // reductions at this point crash ROCm 7.2's instruction selection for gfx950.
+    // second middle order statistic: the smallest key above the first one unless the first is tied
     unsigned c = 0, mna = 0xFFFFFFFFu, mnb = 0xFFFFFFFFu;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      c += (ka[e] <= ra) ? 1u : 0u;
-      c += (kb[e] <= rb) ? 0x10000u : 0u;
-      if (ka[e] > ra) mna = min(mna, ka[e]);
-      if (kb[e] > rb) mnb = min(mnb, kb[e]);
+      const unsigned h = hs[e] ^ 0x80008000u, l = ls[e] ^ 0x80008000u;
+      const unsigned ka = (h << 16) | (l & 0xFFFFu);
+      const unsigned kb = (h & 0xFFFF0000u) | (l >> 16);
+      c += (ka <= keya) ? 1u : 0u;
+      c += (kb <= keyb) ? 0x10000u : 0u;
+      if (ka > keya) mna = min(mna, ka);
+      if (kb > keyb) mnb = min(mnb, kb);
     }
     c = __reduce_add_sync(~0ull, c);
-    unsigned* s_mn = (unsigned*)buf;  // the row buffer is not in use yet
+    // cross-lane minimum through an LDS atomic (once per row pair); the row buffer is still unused
+    unsigned* s_mn = (unsigned*)buf;
     if (lane == 0) { s_mn[0] = 0xFFFFFFFFu; s_mn[1] = 0xFFFFFFFFu; }
     wave_sync();
     atomicMin(&s_mn[0], mna);
@@ -586,18 +655,18 @@ __global__ __launch_bounds__(256) void k_rowfilter(RowArgs a) {
     meda = 0.5f * (meda + v2a);
     medb = 0.5f * (medb + v2b);
   }
-
   // The medians are wave-uniform (SGPR); ROCm 7.2's instruction selection crashes when they flow
   // into the selects / LDS stores below, so pin them into VGPRs.
   asm volatile("" : "+v"(meda), "+v"(medb));
 
-  // in-painted rows -> complex buffer u[m] = x[(m - K) mod N], m in [0, N + 2K]; zero above
+  // ---- in-painted rows -> complex buffer u[m] = x[(m - K) mod N], m in [0, N + 2K]; zero above -----
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int n = lane + kWave * e;
     if (n < N) {
-      const float xa = ((maska >> e) & 1ull) ? meda : key_f32(ka[e]);
-      const float xb = ((maskb >> e) & 1ull) ? medb : key_f32(kb[e]);
+      const unsigned h = hs[e] ^ 0x80008000u, l = ls[e] ^ 0x80008000u;
+      const float xa = ((maska >> e) & 1ull) ? meda : key_f32((h << 16) | (l & 0xFFFFu));
+      const float xb = ((maskb >> e) & 1ull) ? medb : key_f32((h & 0xFFFF0000u) | (l >> 16));
       const float2 z = make_float2(xa, xb);
       buf[K + n] = z;
       if (K > 0) {
@@ -613,34 +682,28 @@ __global__ __launch_bounds__(256) void k_rowfilter(RowArgs a) {
 
   fft_run<CPL>(buf, s_tw, a, lane);
 
-  // V[k] = G1[k] U[k] + G2[k] U[(M - k) mod M], stored re/im-swapped for the inverse transform
+  // ---- V[k] = G1[k] U[k] + G2[k] U[M - k], in place on the pair (k, M - k) ---------------------
+  // G1 is real and even, G2[M - k] = conj(G2[k]) (both modes, dsx_plan.h).  The result is stored
+  // re/im-swapped: the inverse transform runs through the forward passes.
   {
     const float2* g1 = a.g[cfg];
     const float2* g2 = g1 + M;
-    float2 u[CPL], ur[CPL];
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      const int k = lane + kWave * i;
-      if (k < M) {
-        u[i] = buf[k];
-        ur[i] = buf[k == 0 ? 0 : M - k];
-      }
-    }
-    wave_sync();
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      const int k = lane + kWave * i;
-      if (k < M) {
-        const float2 v = dsx_add(dsx_mul(g1[k], u[i]), dsx_mul(g2[k], ur[i]));
-        buf[k] = make_float2(v.y, v.x);
-      }
+    for (int k = lane; 2 * k <= M; k += kWave) {
+      const int kr = (k == 0) ? 0 : M - k;
+      const float2 u = buf[k], ur = buf[kr];
+      const float ga = g1[k].x;
+      const float2 gb = g2[k];
+      const float2 v = make_float2(ga * u.x + gb.x * ur.x - gb.y * ur.y, ga * u.y + gb.x * ur.y + gb.y * ur.x);
+      const float2 vr = make_float2(ga * ur.x + gb.x * u.x + gb.y * u.y, ga * ur.y + gb.x * u.y - gb.y * u.x);
+      buf[k] = make_float2(v.y, v.x);
+      if (kr != k) buf[kr] = make_float2(vr.y, vr.x);
     }
     wave_sync();
   }
 
   fft_run<CPL>(buf, s_tw, a, lane);
 
-  // buf = swap(M * LP): row a <- .y, row b <- .x ; Delta = -(1 - mask) * LP  (filtering.py:215-217)
+  // ---- buf = swap(M * LP): row a <- .y, row b <- .x ; Delta = -(1 - mask) LP (filtering.py:215-217)
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int n = lane + kWave * e;

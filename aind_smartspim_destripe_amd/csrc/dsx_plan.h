@@ -79,13 +79,26 @@ inline double pass_cost(int r) {
     case 3: return 13.3;
     case 4: return 12.0;
     case 5: return 16.0;
+    case 7: return 22.0;
+    case 11: return 32.0;
+    case 13: return 38.0;
+    case 17: return 50.0;
+    case 19: return 56.0;
     default: return 8.0 + 10.0 * r;
   }
+}
+// kernel instantiations of k_rowfilter: complex values per lane (register budget / occupancy)
+inline int cpl_class(int m) {
+  const int cpl = (m + 63) / 64;
+  for (int c : {2, 4, 6, 10, 18, 36}) if (cpl <= c) return c;
+  return 1 << 30;
 }
 inline double fft_cost(int m) {
   double c = 0;
   for (int r : factorize(m)) c += pass_cost(r);
-  return c * m;
+  // the 36-per-lane instantiation runs at one wave per SIMD: roughly 3x slower per instruction
+  const double occ = (cpl_class(m) > 18) ? 3.0 : 1.0;
+  return c * m * occ;
 }
 
 // LP gains in fftpack packed order, folded to the complex bins of a length-n transform:

@@ -24,7 +24,7 @@ static void run_passes(std::vector<dsx_c32>& buf, const std::vector<dsx_c32>& tw
     const int R = radix[pi];
     const float inv_s = 1.0f / (float)s;
     const int nb = M / R;
-    if (R == 2 || R == 3 || R == 4 || R == 5) {
+    if (R == 2 || R == 3 || R == 4 || R == 5 || R == 7 || R == 11 || R == 13 || R == 17 || R == 19) {
       // read phase for every butterfly, then compute + scatter phase (what a wave does)
       std::vector<dsx_c32> regs((size_t)nb * R);
       for (int b = 0; b < nb; ++b) {
@@ -33,6 +33,11 @@ static void run_passes(std::vector<dsx_c32>& buf, const std::vector<dsx_c32>& tw
           case 3: dsx_bfly_load<3>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
           case 4: dsx_bfly_load<4>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
           case 5: dsx_bfly_load<5>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 7: dsx_bfly_load<7>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 11: dsx_bfly_load<11>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 13: dsx_bfly_load<13>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 17: dsx_bfly_load<17>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 19: dsx_bfly_load<19>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
         }
       }
       for (int b = 0; b < nb; ++b) {
@@ -41,6 +46,11 @@ static void run_passes(std::vector<dsx_c32>& buf, const std::vector<dsx_c32>& tw
           case 3: dsx_bfly_store<3>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
           case 4: dsx_bfly_store<4>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
           case 5: dsx_bfly_store<5>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
+          case 7: dsx_bfly_store<7>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
+          case 11: dsx_bfly_store<11>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
+          case 13: dsx_bfly_store<13>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
+          case 17: dsx_bfly_store<17>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
+          case 19: dsx_bfly_store<19>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
         }
       }
     } else {
