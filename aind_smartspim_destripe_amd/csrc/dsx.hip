@@ -150,6 +150,19 @@ hipError_t dispatch_rowfilter(const dsx::RowArgs& a, dim3 grid, hipStream_t s) {
   return launch_rowfilter<36>(a, grid, smem, s);
 }
 
+// Row segmentation of the marching kernels: enough waves to fill the chip for small cohorts,
+// one segment per strip for large ones (each extra segment re-reads a 4-row halo).
+void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg) {
+  const int target_waves = 256 * 16;
+  int want = (target_waves + nb * nstrips - 1) / (nb * nstrips);
+  const int max_seg = std::max(1, rows / 24);
+  want = std::max(1, std::min(want, max_seg));
+  int rps = (rows + want - 1) / want;
+  rps = std::max(1, std::min(rps, 4096));  // uint32 partial sums of k_fwd1_march
+  *rows_per_seg = rps;
+  *nseg = (rows + rps - 1) / rps;
+}
+
 // One cohort of nb planes through the whole chain (asynchronous).
 int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out, int out_dtype,
                int32_t* d_cfg_used) {
@@ -175,14 +188,32 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
     a.lvl = l; a.L = L;
     a.stats = ctx->d_stats;
     a.fg_cutoff = ctx->fg_cutoff;
-    dim3 grid((lp.w + dsx::kFwdTW - 1) / dsx::kFwdTW, (lp.h + dsx::kFwdTH - 1) / dsx::kFwdTH, nb);
     LaunchScope ls(ctx, l == 0 ? KC_FWD1 : KC_FWD);
     if (l > 0) {
+      dim3 grid((lp.w + dsx::kFwdTW - 1) / dsx::kFwdTW, (lp.h + dsx::kFwdTH - 1) / dsx::kFwdTH, nb);
       hipLaunchKernelGGL(dsx::k_dwt_fwd<2>, grid, dim3(256), 0, s, a);
-    } else if (in_dtype == DSX_U16) {
-      hipLaunchKernelGGL(dsx::k_dwt_fwd<0>, grid, dim3(256), 0, s, a);
     } else {
-      hipLaunchKernelGGL(dsx::k_dwt_fwd<1>, grid, dim3(256), 0, s, a);
+      dsx::Fwd1Args f;
+      memset(&f, 0, sizeof(f));
+      f.in = d_in;
+      f.in_plane_stride = (long long)p.H * p.W;
+      f.ws = ctx->d_ws;
+      f.ws_plane_stride = p.plane_floats;
+      f.H = p.H; f.W = p.W;
+      f.aa_off = lp.aa_off; f.da_off = lp.da_off;
+      f.h = lp.h; f.w = lp.w; f.ld = lp.ld;
+      f.minmax = ctx->d_minmax;
+      f.L = L;
+      f.stats = ctx->d_stats;
+      f.fg_cutoff = ctx->fg_cutoff;
+      f.nstrips = (lp.w + dsx::kMarchOut - 1) / dsx::kMarchOut;
+      march_segments(nb, f.nstrips, lp.h, &f.nseg, &f.rows_per_seg);
+      dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
+      if (in_dtype == DSX_U16) {
+        hipLaunchKernelGGL(dsx::k_fwd1_march<0>, grid, dim3(256), 0, s, f);
+      } else {
+        hipLaunchKernelGGL(dsx::k_fwd1_march<1>, grid, dim3(256), 0, s, f);
+      }
     }
     DSX_HIP(hipGetLastError());
   }
@@ -260,8 +291,9 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
   if (ctx->stop_after == 2) return DSX_OK;
 
   // ---- inverse transform of the Delta pyramid + finish ---------------------------------------
-  for (int l = L - 1; l >= 0; --l) {
+  for (int l = L - 1; l >= 1; --l) {
     const dsx::LevelPlan& lp = p.lv[l];
+    const dsx::LevelPlan& lo = p.lv[l - 1];
     dsx::InvArgs a;
     memset(&a, 0, sizeof(a));
     a.ws = ctx->d_ws;
@@ -271,57 +303,44 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
     a.hc = lp.h; a.wc = lp.w; a.ldc = lp.ld;
     a.has_c = (l < L - 1) ? 1 : 0;
     a.has_pyr = 1;
-    if (l > 0) {
-      const dsx::LevelPlan& lo = p.lv[l - 1];
-      a.out_off = lo.aa_off;
-      a.hout = lo.h; a.wout = lo.w; a.ldout = lo.ld;
-      dim3 grid((a.wout + dsx::kInvTW - 1) / dsx::kInvTW, (a.hout + dsx::kInvTH - 1) / dsx::kInvTH, nb);
-      LaunchScope ls(ctx, KC_INV);
-      hipLaunchKernelGGL(dsx::k_idwt<0>, grid, dim3(256), 0, s, a);
-      DSX_HIP(hipGetLastError());
-    } else {
-      a.hout = p.Hout; a.wout = p.Wout; a.ldout = p.Wout;
-      a.img = d_in;
-      a.img_plane_stride = (long long)p.H * p.W;
-      a.H = p.H; a.W = p.W;
-      a.out = d_out;
-      a.out_plane_stride = (long long)p.Hout * p.Wout;
-      a.out_dtype = (out_dtype == DSX_U16) ? 0 : 1;
-      a.flat = ctx->d_flat;
-      a.dark = ctx->d_dark;
-      a.dark_ld = ctx->dark_w;
-      dim3 grid((a.wout + dsx::kInvTW - 1) / dsx::kInvTW, (a.hout + dsx::kInvTH - 1) / dsx::kInvTH, nb);
-      LaunchScope ls(ctx, KC_FINAL);
-      if (in_dtype == DSX_U16) {
-        hipLaunchKernelGGL(dsx::k_idwt<1>, grid, dim3(256), 0, s, a);
-      } else {
-        hipLaunchKernelGGL(dsx::k_idwt<2>, grid, dim3(256), 0, s, a);
-      }
-      DSX_HIP(hipGetLastError());
-    }
-  }
-  if (L == 0) {
-    dsx::InvArgs a;
-    memset(&a, 0, sizeof(a));
-    a.ws = ctx->d_ws;
-    a.ws_plane_stride = p.plane_floats;
-    a.has_pyr = 0;
-    a.hout = p.Hout; a.wout = p.Wout; a.ldout = p.Wout;
-    a.img = d_in;
-    a.img_plane_stride = (long long)p.H * p.W;
-    a.H = p.H; a.W = p.W;
-    a.out = d_out;
-    a.out_plane_stride = (long long)p.Hout * p.Wout;
-    a.out_dtype = (out_dtype == DSX_U16) ? 0 : 1;
-    a.flat = ctx->d_flat;
-    a.dark = ctx->d_dark;
-    a.dark_ld = ctx->dark_w;
+    a.out_off = lo.aa_off;
+    a.hout = lo.h; a.wout = lo.w; a.ldout = lo.ld;
     dim3 grid((a.wout + dsx::kInvTW - 1) / dsx::kInvTW, (a.hout + dsx::kInvTH - 1) / dsx::kInvTH, nb);
+    LaunchScope ls(ctx, KC_INV);
+    hipLaunchKernelGGL(dsx::k_idwt<0>, grid, dim3(256), 0, s, a);
+    DSX_HIP(hipGetLastError());
+  }
+  {
+    dsx::FinalArgs f;
+    memset(&f, 0, sizeof(f));
+    f.ws = ctx->d_ws;
+    f.ws_plane_stride = p.plane_floats;
+    if (L > 0) {
+      const dsx::LevelPlan& lp = p.lv[0];
+      f.c_off = lp.aa_off;
+      f.d_off = lp.da_off;
+      f.hc = lp.h; f.wc = lp.w; f.ldc = lp.ld;
+      f.has_c = (L > 1) ? 1 : 0;
+      f.has_pyr = 1;
+    }
+    f.img = d_in;
+    f.img_plane_stride = (long long)p.H * p.W;
+    f.H = p.H; f.W = p.W;
+    f.out = d_out;
+    f.out_plane_stride = (long long)p.Hout * p.Wout;
+    f.hout = p.Hout; f.wout = p.Wout;
+    f.out_dtype = (out_dtype == DSX_U16) ? 0 : 1;
+    f.flat = ctx->d_flat;
+    f.dark = ctx->d_dark;
+    f.dark_ld = ctx->dark_w;
+    f.nstrips = (p.Wout + dsx::kMarchCols - 1) / dsx::kMarchCols;
+    march_segments(nb, f.nstrips, (p.Hout + 1) / 2, &f.nseg, &f.rows_per_seg);
+    dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
     LaunchScope ls(ctx, KC_FINAL);
     if (in_dtype == DSX_U16) {
-      hipLaunchKernelGGL(dsx::k_idwt<1>, grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(dsx::k_final_march<0>, grid, dim3(256), 0, s, f);
     } else {
-      hipLaunchKernelGGL(dsx::k_idwt<2>, grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(dsx::k_final_march<1>, grid, dim3(256), 0, s, f);
     }
     DSX_HIP(hipGetLastError());
   }

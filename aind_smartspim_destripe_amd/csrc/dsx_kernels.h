@@ -260,6 +260,275 @@ __global__ __launch_bounds__(256) void k_dwt_fwd(FwdArgs a) {
 }
 
 // ================================================================================================
+// K1m: level-1 forward transform, "marching" form (the HBM-heavy level: u16/f32 plane in, aa/da out)
+//
+// One WAVE owns a strip of 256 input columns (4 per lane, one 8/16-byte load per lane and row) and
+// streams down the rows with a 6-row sliding window in registers, so the column (axis-0) filter
+// never touches LDS; only the freshly filtered row pair (a0, d0) goes through a 2 KiB per-wave LDS
+// row to be low-passed along the row (axis 1).  No block barriers, no input halo re-reads along y.
+// Strips advance by 252 input columns = 126 coefficient columns.
+// ================================================================================================
+struct Fwd1Args {
+  const void* in;
+  long long in_plane_stride;
+  float* ws;
+  long long ws_plane_stride;
+  int H, W;
+  long long aa_off, da_off;
+  int h, w, ld;
+  unsigned* minmax;  // [B][L][2], level 0 entry is used
+  int L;
+  PlaneStats* stats;
+  float fg_cutoff;
+  int nstrips, nseg, rows_per_seg;
+};
+
+constexpr int kMarchCols = 256;                 // input columns per wave
+constexpr int kMarchOut = (kMarchCols - 4) / 2;  // 126 coefficient columns per wave
+
+template <int IN_KIND>
+struct MarchStats {
+  // uint16 pixels: exact integer partial sums (a lane sees < 2^14 pixels of < 2^16);
+  // float32 pixels: double partial sums (exact for integer-valued pixels)
+  unsigned cnt = 0;
+  unsigned isum_all = 0, isum_fg = 0;
+  double fsum_all = 0.0, fsum_fg = 0.0;
+  __device__ __forceinline__ void add(float f, float cutoff) {
+    if (IN_KIND == 0) {
+      const unsigned u = (unsigned)f;
+      isum_all += u;
+      if (f >= cutoff) { isum_fg += u; cnt++; }
+    } else {
+      fsum_all += (double)f;
+      if (f >= cutoff) { fsum_fg += (double)f; cnt++; }
+    }
+  }
+};
+
+// Raw (not yet converted) pixels of one row for this lane's 4 columns.
+template <int IN_KIND>
+struct MarchRaw {
+  uint2 u;   // IN_KIND 0: 4 x uint16
+  float4 f;  // IN_KIND 1: 4 x float32
+};
+
+// Column addressing of a lane: 4 consecutive columns gc0 .. gc0+3.  With W % 4 == 0 a group never
+// straddles the plane edge, so a reflected group is an aligned group read in reverse order.
+struct MarchCol {
+  int base;   // first column of the aligned group that is actually loaded
+  bool rev;   // the group is a mirror image (half-sample symmetric extension)
+  bool own;   // this lane accounts these pixels in the fg/bg statistic
+  bool vec;   // vector path usable (W % 4 == 0)
+  int gc0;
+};
+
+__device__ __forceinline__ MarchCol march_col(int gc0, int W, bool lane_owns) {
+  MarchCol c;
+  c.gc0 = gc0;
+  c.vec = (W & 3) == 0;
+  c.rev = false;
+  c.base = gc0;
+  if (gc0 < 0) { c.base = -gc0 - 4; c.rev = true; }
+  else if (gc0 >= W) { c.base = 2 * W - 4 - gc0; c.rev = true; }
+  if (c.base < 0 || c.base + 3 >= W) c.base = 0;  // far outside: outputs of this lane are unused
+  c.own = lane_owns && gc0 >= 0 && gc0 < W;
+  return c;
+}
+
+template <int IN_KIND>
+__device__ __forceinline__ MarchRaw<IN_KIND> march_issue(const void* src, int W, int H, int gr_raw,
+                                                         const MarchCol& c) {
+  MarchRaw<IN_KIND> r;
+  r.u = make_uint2(0u, 0u);
+  r.f = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c.vec) {
+    const long long off = (long long)reflect_idx(gr_raw, H) * W + c.base;
+    if (IN_KIND == 0) r.u = *(const uint2*)((const uint16_t*)src + off);
+    else r.f = *(const float4*)((const float*)src + off);
+  }
+  return r;
+}
+
+// convert a raw row: statistic on owned pixels, then log(1 + x)
+template <int IN_KIND>
+__device__ __forceinline__ void march_consume(const Fwd1Args& a, const void* src, const MarchRaw<IN_KIND>& r,
+                                              int gr_raw, const MarchCol& c, bool row_in_seg,
+                                              MarchStats<IN_KIND>& st, float (&x)[4]) {
+  const bool own_row = row_in_seg && gr_raw >= 0 && gr_raw < a.H;
+  if (c.vec) {
+    float v[4];
+    if (IN_KIND == 0) {
+      v[0] = (float)(r.u.x & 0xFFFFu); v[1] = (float)(r.u.x >> 16);
+      v[2] = (float)(r.u.y & 0xFFFFu); v[3] = (float)(r.u.y >> 16);
+    } else {
+      v[0] = r.f.x; v[1] = r.f.y; v[2] = r.f.z; v[3] = r.f.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float f = c.rev ? v[3 - e] : v[e];
+      if (own_row && c.own) st.add(f, a.fg_cutoff);
+      x[e] = __logf(1.0f + f);
+    }
+  } else {
+    const int gr = reflect_idx(gr_raw, a.H);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int gc_raw = c.gc0 + e;
+      const int gc = reflect_idx(gc_raw, a.W);
+      const long long off = (long long)gr * a.W + gc;
+      const float f = (IN_KIND == 0) ? (float)((const uint16_t*)src)[off] : ((const float*)src)[off];
+      if (own_row && c.own && gc_raw >= 0 && gc_raw < a.W) st.add(f, a.fg_cutoff);
+      x[e] = __logf(1.0f + f);
+    }
+  }
+}
+
+// IN_KIND: 0 = uint16 pixels, 1 = float32 pixels
+template <int IN_KIND>
+__global__ __launch_bounds__(256) void k_fwd1_march(Fwd1Args a) {
+  __shared__ __attribute__((aligned(16))) float s_row[4][2][2][kMarchCols / 2];  // [wave][lo|hi][parity][col/2]
+  constexpr float LO[6] = DSX_DEC_LO;
+  constexpr float HI[6] = DSX_DEC_HI;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= a.nstrips * a.nseg) return;
+  const int strip = item % a.nstrips, seg = item / a.nstrips;
+  const int plane = blockIdx.y;
+  const int i_begin = seg * a.rows_per_seg;
+  const int i_end = min(a.h, i_begin + a.rows_per_seg);
+  if (i_begin >= i_end) return;
+  const int j0 = kMarchOut * strip;
+  // lane 0 re-reads the last 4 columns of the previous strip and does not account them
+  const MarchCol col = march_col(2 * j0 - 4 + 4 * lane, a.W, lane >= 1);
+  const void* src = (IN_KIND == 0) ? (const void*)((const uint16_t*)a.in + plane * a.in_plane_stride)
+                                   : (const void*)((const float*)a.in + plane * a.in_plane_stride);
+  float* aa = a.ws + plane * a.ws_plane_stride + a.aa_off;
+  float* da = a.ws + plane * a.ws_plane_stride + a.da_off;
+  float2* sE[2] = {(float2*)s_row[wave][0][0], (float2*)s_row[wave][1][0]};
+  float2* sO[2] = {(float2*)s_row[wave][0][1], (float2*)s_row[wave][1][1]};
+
+  MarchStats<IN_KIND> st;
+  float win[6][4];  // sliding window of log(1 + pixel): rows 2i-4 .. 2i+1, this lane's 4 columns
+  // prologue: rows 2 i_begin - 4 .. 2 i_begin - 1 (owned by the previous segment / outside the plane)
+  {
+    MarchRaw<IN_KIND> pr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pr[r] = march_issue<IN_KIND>(src, a.W, a.H, 2 * i_begin - 4 + r, col);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      march_consume<IN_KIND>(a, src, pr[r], 2 * i_begin - 4 + r, col, false, st, win[r]);
+  }
+
+  float qmin = __builtin_huge_valf(), qmax = 0.f;
+  const int jj0 = 2 * lane;  // this lane's two output columns (lanes 0..62)
+  const bool out_lane = lane < kMarchOut / 2;
+
+  // One output row i: the raw rows 2i, 2i+1 become window slots (r4, r5); r0..r5 = oldest..newest.
+  auto step = [&](int i, const MarchRaw<IN_KIND>& raw0, const MarchRaw<IN_KIND>& raw1, float (&r0)[4],
+                  float (&r1)[4], float (&r2)[4], float (&r3)[4], float (&r4)[4], float (&r5)[4]) {
+    march_consume<IN_KIND>(a, src, raw0, 2 * i, col, true, st, r4);
+    march_consume<IN_KIND>(a, src, raw1, 2 * i + 1, col, true, st, r5);
+    // axis 0: out = sum_k f[k] * x[2i + 1 - k] = sum_k f[k] * r(5 - k)
+    float lo[4], hi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lo[e] = LO[0] * r5[e];
+      hi[e] = HI[0] * r5[e];
+      lo[e] = fmaf(LO[1], r4[e], lo[e]); hi[e] = fmaf(HI[1], r4[e], hi[e]);
+      lo[e] = fmaf(LO[2], r3[e], lo[e]); hi[e] = fmaf(HI[2], r3[e], hi[e]);
+      lo[e] = fmaf(LO[3], r2[e], lo[e]); hi[e] = fmaf(HI[3], r2[e], hi[e]);
+      lo[e] = fmaf(LO[4], r1[e], lo[e]); hi[e] = fmaf(HI[4], r1[e], hi[e]);
+      lo[e] = fmaf(LO[5], r0[e], lo[e]); hi[e] = fmaf(HI[5], r0[e], hi[e]);
+    }
+    sE[0][lane] = make_float2(lo[0], lo[2]);
+    sO[0][lane] = make_float2(lo[1], lo[3]);
+    sE[1][lane] = make_float2(hi[0], hi[2]);
+    sO[1][lane] = make_float2(hi[1], hi[3]);
+    wave_sync();
+    // axis 1, low-pass only: out[jj] = LO0 O[jj+2] + LO1 E[jj+2] + LO2 O[jj+1] + LO3 E[jj+1] + LO4 O[jj] + LO5 E[jj]
+    float res[2][2];
+    if (out_lane) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float2 e01 = sE[b][lane], e23 = sE[b][lane + 1];
+        const float2 o01 = sO[b][lane], o23 = sO[b][lane + 1];
+        float v0 = LO[0] * o23.x;
+        v0 = fmaf(LO[1], e23.x, v0); v0 = fmaf(LO[2], o01.y, v0); v0 = fmaf(LO[3], e01.y, v0);
+        v0 = fmaf(LO[4], o01.x, v0); v0 = fmaf(LO[5], e01.x, v0);
+        float v1 = LO[0] * o23.y;
+        v1 = fmaf(LO[1], e23.y, v1); v1 = fmaf(LO[2], o23.x, v1); v1 = fmaf(LO[3], e23.x, v1);
+        v1 = fmaf(LO[4], o01.y, v1); v1 = fmaf(LO[5], e01.y, v1);
+        res[b][0] = v0;
+        res[b][1] = v1;
+      }
+    }
+    wave_sync();
+    if (out_lane) {
+      const int j = j0 + jj0;
+      const long long o = (long long)i * a.ld + j;
+      if (j + 1 < a.w) {
+        *(float2*)(aa + o) = make_float2(res[0][0], res[0][1]);
+        *(float2*)(da + o) = make_float2(res[1][0], res[1][1]);
+        const float q0 = res[1][0] * res[1][0], q1 = res[1][1] * res[1][1];
+        qmin = fminf(qmin, fminf(q0, q1));
+        qmax = fmaxf(qmax, fmaxf(q0, q1));
+      } else if (j < a.w) {
+        aa[o] = res[0][0];
+        da[o] = res[1][0];
+        const float q0 = res[1][0] * res[1][0];
+        qmin = fminf(qmin, q0);
+        qmax = fmaxf(qmax, q0);
+      }
+    }
+  };
+
+  // software prefetch: the 6 rows of the NEXT group of 3 output rows are in flight while the
+  // current group is filtered (the symmetric extension keeps every prefetched address valid)
+  MarchRaw<IN_KIND> nxt[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND>(src, a.W, a.H, 2 * i_begin + r, col);
+  for (int i = i_begin; i < i_end; i += 3) {
+    MarchRaw<IN_KIND> cur[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) cur[r] = nxt[r];
+    if (i + 3 < i_end) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND>(src, a.W, a.H, 2 * (i + 3) + r, col);
+    }
+    step(i, cur[0], cur[1], win[0], win[1], win[2], win[3], win[4], win[5]);
+    if (i + 1 < i_end) step(i + 1, cur[2], cur[3], win[2], win[3], win[4], win[5], win[0], win[1]);
+    if (i + 2 < i_end) step(i + 2, cur[4], cur[5], win[4], win[5], win[0], win[1], win[2], win[3]);
+  }
+
+  qmin = wave_min_f32(qmin);
+  qmax = wave_max_f32(qmax);
+  double s_all, s_fg;
+  if (IN_KIND == 0) {
+    s_all = (double)st.isum_all;
+    s_fg = (double)st.isum_fg;
+  } else {
+    s_all = st.fsum_all;
+    s_fg = st.fsum_fg;
+  }
+  s_all = wave_sum_f64(s_all);
+  s_fg = wave_sum_f64(s_fg);
+  const unsigned cnt = __reduce_add_sync(~0ull, st.cnt);
+  if (lane == 0) {
+    unsigned* mm = a.minmax + (long long)plane * a.L * 2;
+    if (qmin <= qmax) {
+      atomicMax(&mm[0], ~as_u32(qmin));
+      atomicMax(&mm[1], as_u32(qmax));
+    }
+    PlaneStats* ps = a.stats + plane;
+    if (s_all != 0.0) atomicAdd(&ps->sum_all, s_all);
+    if (cnt != 0) {
+      atomicAdd(&ps->sum_fg, s_fg);
+      atomicAdd(&ps->cnt_fg, (unsigned long long)cnt);
+    }
+  }
+}
+
+// ================================================================================================
 // K2: histogram of q = cH^2, numpy.histogram(bins=256) rule in float32
 // ================================================================================================
 struct HistArgs {
@@ -825,6 +1094,227 @@ __global__ __launch_bounds__(256) void k_idwt(InvArgs a) {
         ((float*)a.out)[o] = r;
       }
     }
+  }
+}
+
+// ================================================================================================
+// K5m/K6m: last synthesis level, "marching" form.  One wave owns 256 result columns (4 per lane)
+// and streams down the coefficient rows p: the row (axis-1) synthesis of c_1 / Delta_1 is done
+// in registers (3 taps), a 3-row register window feeds the column (axis-0) synthesis, and the
+// finish  (1 + x) exp(c0) + 1  (+ shading, cast) is fused.  No LDS, no barriers.
+// ================================================================================================
+struct FinalArgs {
+  const float* ws;
+  long long ws_plane_stride;
+  long long c_off, d_off;
+  int hc, wc, ldc;
+  int has_c, has_pyr;
+  const void* img;
+  long long img_plane_stride;
+  int H, W;
+  void* out;
+  long long out_plane_stride;
+  int hout, wout;
+  int out_dtype;  // 0 = uint16, 1 = float32
+  const float* flat;
+  const float* dark;
+  int dark_ld;
+  int nstrips, nseg, rows_per_seg;  // segments in coefficient rows p
+};
+
+struct FinalRawC {  // raw coefficients q .. q+3 of one row of c and Delta
+  float2 c01, c23, d01, d23;
+};
+template <int IN_KIND>
+struct FinalRawI {  // raw pixels x0 .. x0+3 of one plane row
+  uint2 u;
+  float4 f;
+};
+
+__device__ __forceinline__ void final_coeff_row(const FinalArgs& a, const float* base, int p, int q, bool on,
+                                                bool vec, float2& lo, float2& hi) {
+  lo = make_float2(0.f, 0.f);
+  hi = make_float2(0.f, 0.f);
+  if (!on || p >= a.hc) return;
+  const float* row = base + (long long)p * a.ldc;
+  if (vec) {
+    lo = *(const float2*)(row + q);
+    hi = *(const float2*)(row + q + 2);
+  } else {
+    if (q < a.wc) lo.x = row[q];
+    if (q + 1 < a.wc) lo.y = row[q + 1];
+    if (q + 2 < a.wc) hi.x = row[q + 2];
+    if (q + 3 < a.wc) hi.y = row[q + 3];
+  }
+}
+
+// row synthesis of 4 result columns x = 4t .. 4t+3 from coefficients q .. q+3 (q = 2t):
+// out[2 qq + b] = in[qq] rl[4+b] + in[qq+1] rl[2+b] + in[qq+2] rl[b]
+__device__ __forceinline__ void final_xsynth(float2 lo, float2 hi, float (&o)[4]) {
+  constexpr float RL[6] = DSX_REC_LO;
+  o[0] = fmaf(lo.x, RL[4], fmaf(lo.y, RL[2], hi.x * RL[0]));
+  o[1] = fmaf(lo.x, RL[5], fmaf(lo.y, RL[3], hi.x * RL[1]));
+  o[2] = fmaf(lo.y, RL[4], fmaf(hi.x, RL[2], hi.y * RL[0]));
+  o[3] = fmaf(lo.y, RL[5], fmaf(hi.x, RL[3], hi.y * RL[1]));
+}
+
+__device__ __forceinline__ float final_px(const FinalArgs& a, float c0, float x, int gy, int gx) {
+  float v = fmaf(1.0f + x, __expf(c0), 1.0f);  // exp(log(1 + x) + c0) + 1   (filtering.py:222)
+  if (a.flat != nullptr) {                     // flatfield_correction, filtering.py:399-412
+    const float d = a.dark[(long long)gy * a.dark_ld + gx];
+    v = (v > d) ? (v - d) : 0.f;
+    v = v / a.flat[(long long)gy * a.wout + gx];
+    v = fminf(fmaxf(v, 0.f), 65535.f);
+  }
+  return v;
+}
+
+// IN_KIND: 0 = uint16 pixels, 1 = float32 pixels
+template <int IN_KIND>
+__global__ __launch_bounds__(256) void k_final_march(FinalArgs a) {
+  constexpr float RL[6] = DSX_REC_LO;
+  constexpr float RH[6] = DSX_REC_HI;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= a.nstrips * a.nseg) return;
+  const int strip = item % a.nstrips, seg = item / a.nstrips;
+  const int plane = blockIdx.y;
+  const int np = (a.hout + 1) >> 1;  // coefficient rows that produce result rows
+  const int p_begin = seg * a.rows_per_seg;
+  const int p_end = min(np, p_begin + a.rows_per_seg);
+  if (p_begin >= p_end) return;
+  const int x0 = kMarchCols * strip + 4 * lane;
+  if (x0 >= a.wout) return;
+  const int q = x0 >> 1;
+  const float* cbase = a.ws + plane * a.ws_plane_stride + a.c_off;
+  const float* dbase = a.ws + plane * a.ws_plane_stride + a.d_off;
+  const bool pyr = a.has_pyr != 0;
+  const bool has_c = pyr && a.has_c;
+  const bool vec_c = q + 3 < a.wc;
+  const bool vec_in = ((a.W & 3) == 0) && (x0 + 3 < a.W);
+  const bool vec_out = ((a.wout & 3) == 0) && (x0 + 3 < a.wout);
+  const long long img_plane = plane * a.img_plane_stride;
+
+  auto issue_c = [&](int p) {
+    FinalRawC r;
+    final_coeff_row(a, cbase, p, q, has_c, vec_c, r.c01, r.c23);
+    final_coeff_row(a, dbase, p, q, pyr, vec_c, r.d01, r.d23);
+    return r;
+  };
+  auto issue_i = [&](int gy) {
+    FinalRawI<IN_KIND> r;
+    r.u = make_uint2(0u, 0u);
+    r.f = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec_in) {
+      const long long off = img_plane + (long long)min(gy, a.H - 1) * a.W + x0;
+      if (IN_KIND == 0) r.u = *(const uint2*)((const uint16_t*)a.img + off);
+      else r.f = *(const float4*)((const float*)a.img + off);
+    }
+    return r;
+  };
+
+  float A[3][4], D[3][4];  // row-synthesised c and Delta rows p, p+1, p+2 (window)
+  {
+    const FinalRawC r0 = issue_c(p_begin), r1 = issue_c(p_begin + 1);
+    final_xsynth(r0.c01, r0.c23, A[0]);
+    final_xsynth(r0.d01, r0.d23, D[0]);
+    final_xsynth(r1.c01, r1.c23, A[1]);
+    final_xsynth(r1.d01, r1.d23, D[1]);
+  }
+
+  auto emit_row = [&](int gy, const FinalRawI<IN_KIND>& raw, const float (&c0)[4]) {
+    if (gy >= a.hout) return;
+    float px[4];
+    if (vec_in) {
+      if (IN_KIND == 0) {
+        px[0] = (float)(raw.u.x & 0xFFFFu); px[1] = (float)(raw.u.x >> 16);
+        px[2] = (float)(raw.u.y & 0xFFFFu); px[3] = (float)(raw.u.y >> 16);
+      } else {
+        px[0] = raw.f.x; px[1] = raw.f.y; px[2] = raw.f.z; px[3] = raw.f.w;
+      }
+    } else {
+      const int sy = min(gy, a.H - 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int sx = min(x0 + e, a.W - 1);  // an odd plane grows by one replicated column / row
+        const long long off = img_plane + (long long)sy * a.W + sx;
+        px[e] = (IN_KIND == 0) ? (float)((const uint16_t*)a.img)[off] : ((const float*)a.img)[off];
+      }
+    }
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (x0 + e < a.wout) ? final_px(a, c0[e], px[e], gy, x0 + e) : 0.f;
+    const long long o = plane * a.out_plane_stride + (long long)gy * a.wout + x0;
+    if (a.out_dtype == 0) {
+      unsigned u[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u[e] = (unsigned)(int)fminf(fmaxf(r[e], 0.f), 65535.f);
+      if (vec_out) {
+        *(uint2*)((uint16_t*)a.out + o) = make_uint2(u[0] | (u[1] << 16), u[2] | (u[3] << 16));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (x0 + e < a.wout) ((uint16_t*)a.out)[o + e] = (uint16_t)u[e];
+      }
+    } else {
+      if (vec_out) {
+        *(float4*)((float*)a.out + o) = make_float4(r[0], r[1], r[2], r[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (x0 + e < a.wout) ((float*)a.out)[o + e] = r[e];
+      }
+    }
+  };
+
+  // one coefficient row p -> result rows 2p, 2p+1; (A0, A1, A2) = window rows p, p+1, p+2
+  auto step = [&](int p, const FinalRawC& rc, const FinalRawI<IN_KIND>& ri0, const FinalRawI<IN_KIND>& ri1,
+                  float (&A0)[4], float (&A1)[4], float (&A2)[4], float (&D0)[4], float (&D1)[4],
+                  float (&D2)[4]) {
+    final_xsynth(rc.c01, rc.c23, A2);
+    final_xsynth(rc.d01, rc.d23, D2);
+    float even[4], odd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // out[2p + b] = sum_j A[p+j] rl[4 - 2j + b] + D[p+j] rh[4 - 2j + b]
+      float v0 = A0[e] * RL[4];
+      v0 = fmaf(A1[e], RL[2], v0); v0 = fmaf(A2[e], RL[0], v0);
+      v0 = fmaf(D0[e], RH[4], v0); v0 = fmaf(D1[e], RH[2], v0); v0 = fmaf(D2[e], RH[0], v0);
+      float v1 = A0[e] * RL[5];
+      v1 = fmaf(A1[e], RL[3], v1); v1 = fmaf(A2[e], RL[1], v1);
+      v1 = fmaf(D0[e], RH[5], v1); v1 = fmaf(D1[e], RH[3], v1); v1 = fmaf(D2[e], RH[1], v1);
+      even[e] = v0;
+      odd[e] = v1;
+    }
+    emit_row(2 * p, ri0, even);
+    emit_row(2 * p + 1, ri1, odd);
+  };
+
+  // software prefetch: coefficient rows p+2..p+4 and plane rows 2p..2p+5 of the NEXT group of three
+  // steps are in flight while the current group is synthesised (out-of-range rows load nothing /
+  // a clamped row, their results are never stored)
+  FinalRawC nc[3];
+  FinalRawI<IN_KIND> ni[6];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) nc[r] = issue_c(p_begin + 2 + r);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) ni[r] = issue_i(2 * p_begin + r);
+  for (int p = p_begin; p < p_end; p += 3) {
+    FinalRawC cc[3];
+    FinalRawI<IN_KIND> ci[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cc[r] = nc[r];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) ci[r] = ni[r];
+    if (p + 3 < p_end) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) nc[r] = issue_c(p + 5 + r);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) ni[r] = issue_i(2 * (p + 3) + r);
+    }
+    step(p, cc[0], ci[0], ci[1], A[0], A[1], A[2], D[0], D[1], D[2]);
+    if (p + 1 < p_end) step(p + 1, cc[1], ci[2], ci[3], A[1], A[2], A[0], D[1], D[2], D[0]);
+    if (p + 2 < p_end) step(p + 2, cc[2], ci[4], ci[5], A[2], A[0], A[1], D[2], D[0], D[1]);
   }
 }
 
