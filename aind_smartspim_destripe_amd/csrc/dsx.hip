@@ -20,8 +20,8 @@ namespace {
 thread_local std::string g_init_error;
 
 enum KernelClass { KC_FWD1 = 0, KC_FWD, KC_HIST, KC_OTSU, KC_ROW, KC_INV, KC_FINAL, KC_COUNT };
-const char* kClassNames[KC_COUNT] = {"k_dwt_fwd(level1)", "k_dwt_fwd(coarse)", "k_hist", "k_otsu",
-                                     "k_rowfilter",       "k_idwt(pyramid)",   "k_idwt(final)"};
+const char* kClassNames[KC_COUNT] = {"k_fwd_march(level1)", "k_fwd_march(coarse)", "k_hist", "k_otsu",
+                                     "k_rowfilter",       "k_inv_march(pyramid)", "k_inv_march(final)"};
 
 struct ProfRec {
   int cls;
@@ -124,8 +124,21 @@ struct LaunchScope {
   }
 };
 
+// Waves (row pairs) per block: they share one twiddle table in LDS; pick the count that puts the
+// most waves on a CU (160 KiB LDS, at most 16 waves at 4 waves per SIMD).
+int rowfilter_waves_per_block(int M) {
+  int best_w = 4, best_total = 0;
+  for (int w = 4; w <= dsx::kRowMaxWaves; ++w) {
+    const size_t bytes = (size_t)M * (w + 1) * sizeof(float2);
+    const int blocks = (int)std::min<size_t>(160 * 1024 / bytes, 8);
+    const int total = std::min(blocks * w, 16);
+    if (total > best_total) { best_total = total; best_w = w; }
+  }
+  return best_w;
+}
+
 template <int CPL>
-hipError_t launch_rowfilter(const dsx::RowArgs& a, dim3 grid, size_t smem, hipStream_t s) {
+hipError_t launch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s) {
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -135,19 +148,21 @@ hipError_t launch_rowfilter(const dsx::RowArgs& a, dim3 grid, size_t smem, hipSt
     if (e != hipSuccess) return e;
     attr_set[dev & 63] = true;
   }
-  hipLaunchKernelGGL(dsx::k_rowfilter<CPL>, grid, dim3(256), smem, s, a);
+  const int wpb = (CPL > 18) ? 4 : rowfilter_waves_per_block(a.M);
+  const size_t smem = (size_t)a.M * (wpb + 1) * sizeof(float2);
+  dim3 grid((npairs + wpb - 1) / wpb, nb);
+  hipLaunchKernelGGL(dsx::k_rowfilter<CPL>, grid, dim3(64 * wpb), smem, s, a);
   return hipGetLastError();
 }
 
-hipError_t dispatch_rowfilter(const dsx::RowArgs& a, dim3 grid, hipStream_t s) {
-  const size_t smem = (size_t)a.M * 5 * sizeof(float2);
+hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s) {
   const int cpl = (a.M + 63) / 64;
-  if (cpl <= 2) return launch_rowfilter<2>(a, grid, smem, s);
-  if (cpl <= 4) return launch_rowfilter<4>(a, grid, smem, s);
-  if (cpl <= 6) return launch_rowfilter<6>(a, grid, smem, s);
-  if (cpl <= 10) return launch_rowfilter<10>(a, grid, smem, s);
-  if (cpl <= 18) return launch_rowfilter<18>(a, grid, smem, s);
-  return launch_rowfilter<36>(a, grid, smem, s);
+  if (cpl <= 2) return launch_rowfilter<2>(a, npairs, nb, s);
+  if (cpl <= 4) return launch_rowfilter<4>(a, npairs, nb, s);
+  if (cpl <= 6) return launch_rowfilter<6>(a, npairs, nb, s);
+  if (cpl <= 10) return launch_rowfilter<10>(a, npairs, nb, s);
+  if (cpl <= 18) return launch_rowfilter<18>(a, npairs, nb, s);
+  return launch_rowfilter<36>(a, npairs, nb, s);
 }
 
 // Row segmentation of the marching kernels: enough waves to fill the chip for small cohorts,
@@ -174,46 +189,30 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
   // ---- forward transform ------------------------------------------------------------------
   for (int l = 0; l < L; ++l) {
     const dsx::LevelPlan& lp = p.lv[l];
-    dsx::FwdArgs a;
-    memset(&a, 0, sizeof(a));
-    a.in = d_in;
-    a.in_plane_stride = (long long)p.H * p.W;
-    a.ws = ctx->d_ws;
-    a.ws_plane_stride = p.plane_floats;
-    a.in_off = (l > 0) ? p.lv[l - 1].aa_off : 0;
-    a.hin = lp.hin; a.win = lp.win; a.ldin = lp.ldin;
-    a.aa_off = lp.aa_off; a.da_off = lp.da_off;
-    a.h = lp.h; a.w = lp.w; a.ld = lp.ld;
-    a.minmax = ctx->d_minmax;
-    a.lvl = l; a.L = L;
-    a.stats = ctx->d_stats;
-    a.fg_cutoff = ctx->fg_cutoff;
+    dsx::Fwd1Args f;
+    memset(&f, 0, sizeof(f));
+    f.in = d_in;
+    f.in_plane_stride = (long long)p.H * p.W;
+    f.ws = ctx->d_ws;
+    f.ws_plane_stride = p.plane_floats;
+    f.in_off = (l > 0) ? p.lv[l - 1].aa_off : 0;
+    f.H = lp.hin; f.W = lp.win; f.ldin = lp.ldin;
+    f.aa_off = lp.aa_off; f.da_off = lp.da_off;
+    f.h = lp.h; f.w = lp.w; f.ld = lp.ld;
+    f.minmax = ctx->d_minmax;
+    f.lvl = l; f.L = L;
+    f.stats = ctx->d_stats;
+    f.fg_cutoff = ctx->fg_cutoff;
+    f.nstrips = (lp.w + dsx::kMarchOut - 1) / dsx::kMarchOut;
+    march_segments(nb, f.nstrips, lp.h, &f.nseg, &f.rows_per_seg);
+    dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
     LaunchScope ls(ctx, l == 0 ? KC_FWD1 : KC_FWD);
     if (l > 0) {
-      dim3 grid((lp.w + dsx::kFwdTW - 1) / dsx::kFwdTW, (lp.h + dsx::kFwdTH - 1) / dsx::kFwdTH, nb);
-      hipLaunchKernelGGL(dsx::k_dwt_fwd<2>, grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(dsx::k_fwd_march<2>, grid, dim3(256), 0, s, f);
+    } else if (in_dtype == DSX_U16) {
+      hipLaunchKernelGGL(dsx::k_fwd_march<0>, grid, dim3(256), 0, s, f);
     } else {
-      dsx::Fwd1Args f;
-      memset(&f, 0, sizeof(f));
-      f.in = d_in;
-      f.in_plane_stride = (long long)p.H * p.W;
-      f.ws = ctx->d_ws;
-      f.ws_plane_stride = p.plane_floats;
-      f.H = p.H; f.W = p.W;
-      f.aa_off = lp.aa_off; f.da_off = lp.da_off;
-      f.h = lp.h; f.w = lp.w; f.ld = lp.ld;
-      f.minmax = ctx->d_minmax;
-      f.L = L;
-      f.stats = ctx->d_stats;
-      f.fg_cutoff = ctx->fg_cutoff;
-      f.nstrips = (lp.w + dsx::kMarchOut - 1) / dsx::kMarchOut;
-      march_segments(nb, f.nstrips, lp.h, &f.nseg, &f.rows_per_seg);
-      dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
-      if (in_dtype == DSX_U16) {
-        hipLaunchKernelGGL(dsx::k_fwd1_march<0>, grid, dim3(256), 0, s, f);
-      } else {
-        hipLaunchKernelGGL(dsx::k_fwd1_march<1>, grid, dim3(256), 0, s, f);
-      }
+      hipLaunchKernelGGL(dsx::k_fwd_march<1>, grid, dim3(256), 0, s, f);
     }
     DSX_HIP(hipGetLastError());
   }
@@ -284,63 +283,53 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
     a.g[1] = (const float2*)(ctx->d_consts + lp.g_off[1]);
     a.inv_M = 1.0f / (float)lp.M;
     const int npairs = (lp.h + 1) / 2;
-    dim3 grid((npairs + 3) / 4, nb);
     LaunchScope ls(ctx, KC_ROW);
-    DSX_HIP(dispatch_rowfilter(a, grid, s));
+    DSX_HIP(dispatch_rowfilter(a, npairs, nb, s));
   }
   if (ctx->stop_after == 2) return DSX_OK;
 
   // ---- inverse transform of the Delta pyramid + finish ---------------------------------------
-  for (int l = L - 1; l >= 1; --l) {
-    const dsx::LevelPlan& lp = p.lv[l];
-    const dsx::LevelPlan& lo = p.lv[l - 1];
-    dsx::InvArgs a;
-    memset(&a, 0, sizeof(a));
-    a.ws = ctx->d_ws;
-    a.ws_plane_stride = p.plane_floats;
-    a.c_off = lp.aa_off;
-    a.d_off = lp.da_off;
-    a.hc = lp.h; a.wc = lp.w; a.ldc = lp.ld;
-    a.has_c = (l < L - 1) ? 1 : 0;
-    a.has_pyr = 1;
-    a.out_off = lo.aa_off;
-    a.hout = lo.h; a.wout = lo.w; a.ldout = lo.ld;
-    dim3 grid((a.wout + dsx::kInvTW - 1) / dsx::kInvTW, (a.hout + dsx::kInvTH - 1) / dsx::kInvTH, nb);
-    LaunchScope ls(ctx, KC_INV);
-    hipLaunchKernelGGL(dsx::k_idwt<0>, grid, dim3(256), 0, s, a);
-    DSX_HIP(hipGetLastError());
-  }
-  {
+  for (int l = L - 1; l >= (L > 0 ? 0 : -1); --l) {
     dsx::FinalArgs f;
     memset(&f, 0, sizeof(f));
     f.ws = ctx->d_ws;
     f.ws_plane_stride = p.plane_floats;
-    if (L > 0) {
-      const dsx::LevelPlan& lp = p.lv[0];
+    if (l >= 0) {
+      const dsx::LevelPlan& lp = p.lv[l];
       f.c_off = lp.aa_off;
       f.d_off = lp.da_off;
       f.hc = lp.h; f.wc = lp.w; f.ldc = lp.ld;
-      f.has_c = (L > 1) ? 1 : 0;
+      f.has_c = (l < L - 1) ? 1 : 0;
       f.has_pyr = 1;
     }
-    f.img = d_in;
-    f.img_plane_stride = (long long)p.H * p.W;
-    f.H = p.H; f.W = p.W;
-    f.out = d_out;
-    f.out_plane_stride = (long long)p.Hout * p.Wout;
-    f.hout = p.Hout; f.wout = p.Wout;
-    f.out_dtype = (out_dtype == DSX_U16) ? 0 : 1;
-    f.flat = ctx->d_flat;
-    f.dark = ctx->d_dark;
-    f.dark_ld = ctx->dark_w;
-    f.nstrips = (p.Wout + dsx::kMarchCols - 1) / dsx::kMarchCols;
-    march_segments(nb, f.nstrips, (p.Hout + 1) / 2, &f.nseg, &f.rows_per_seg);
-    dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
-    LaunchScope ls(ctx, KC_FINAL);
-    if (in_dtype == DSX_U16) {
-      hipLaunchKernelGGL(dsx::k_final_march<0>, grid, dim3(256), 0, s, f);
+    const bool last = (l <= 0);
+    if (!last) {
+      const dsx::LevelPlan& lo = p.lv[l - 1];
+      f.ws_out = ctx->d_ws;
+      f.out_off = lo.aa_off;
+      f.hout = lo.h; f.wout = lo.w; f.ldout = lo.ld;
     } else {
-      hipLaunchKernelGGL(dsx::k_final_march<1>, grid, dim3(256), 0, s, f);
+      f.img = d_in;
+      f.img_plane_stride = (long long)p.H * p.W;
+      f.H = p.H; f.W = p.W;
+      f.out = d_out;
+      f.out_plane_stride = (long long)p.Hout * p.Wout;
+      f.hout = p.Hout; f.wout = p.Wout;
+      f.out_dtype = (out_dtype == DSX_U16) ? 0 : 1;
+      f.flat = ctx->d_flat;
+      f.dark = ctx->d_dark;
+      f.dark_ld = ctx->dark_w;
+    }
+    f.nstrips = (f.wout + dsx::kMarchCols - 1) / dsx::kMarchCols;
+    march_segments(nb, f.nstrips, (f.hout + 1) / 2, &f.nseg, &f.rows_per_seg);
+    dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
+    LaunchScope ls(ctx, last ? KC_FINAL : KC_INV);
+    if (!last) {
+      hipLaunchKernelGGL(dsx::k_inv_march<2>, grid, dim3(256), 0, s, f);
+    } else if (in_dtype == DSX_U16) {
+      hipLaunchKernelGGL(dsx::k_inv_march<0>, grid, dim3(256), 0, s, f);
+    } else {
+      hipLaunchKernelGGL(dsx::k_inv_march<1>, grid, dim3(256), 0, s, f);
     }
     DSX_HIP(hipGetLastError());
   }

@@ -269,15 +269,16 @@ __global__ __launch_bounds__(256) void k_dwt_fwd(FwdArgs a) {
 // Strips advance by 252 input columns = 126 coefficient columns.
 // ================================================================================================
 struct Fwd1Args {
-  const void* in;
+  const void* in;            // IN_KIND 0/1: pixels [B][H][W]
   long long in_plane_stride;
   float* ws;
   long long ws_plane_stride;
-  int H, W;
+  long long in_off;          // IN_KIND 2: offset of aa_{l-1} inside a plane's workspace
+  int H, W, ldin;            // input rows, valid columns, row pitch (elements)
   long long aa_off, da_off;
   int h, w, ld;
-  unsigned* minmax;  // [B][L][2], level 0 entry is used
-  int L;
+  unsigned* minmax;  // [B][L][2]
+  int lvl, L;
   PlaneStats* stats;
   float fg_cutoff;
   int nstrips, nseg, rows_per_seg;
@@ -288,7 +289,7 @@ constexpr int kMarchOut = (kMarchCols - 4) / 2;  // 126 coefficient columns per 
 
 template <int IN_KIND>
 struct MarchStats {
-  // uint16 pixels: exact integer partial sums (a lane sees < 2^14 pixels of < 2^16);
+  // uint16 pixels: exact integer partial sums (a lane sees < 2^15 pixels of < 2^16);
   // float32 pixels: double partial sums (exact for integer-valued pixels)
   unsigned cnt = 0;
   unsigned isum_all = 0, isum_fg = 0;
@@ -305,87 +306,111 @@ struct MarchStats {
   }
 };
 
-// Raw (not yet converted) pixels of one row for this lane's 4 columns.
-template <int IN_KIND>
+// Raw (not yet converted) values of one row for this lane's 4 columns.
 struct MarchRaw {
-  uint2 u;   // IN_KIND 0: 4 x uint16
-  float4 f;  // IN_KIND 1: 4 x float32
+  float4 f;  // IN_KIND 1/2: 4 x float32; IN_KIND 0: .x/.y carry the bits of 4 x uint16
 };
 
-// Column addressing of a lane: 4 consecutive columns gc0 .. gc0+3.  With W % 4 == 0 a group never
-// straddles the plane edge, so a reflected group is an aligned group read in reverse order.
+// Column addressing of a lane: 4 consecutive columns gc0 .. gc0+3.
 struct MarchCol {
-  int base;   // first column of the aligned group that is actually loaded
-  bool rev;   // the group is a mirror image (half-sample symmetric extension)
-  bool own;   // this lane accounts these pixels in the fg/bg statistic
-  bool vec;   // vector path usable (W % 4 == 0)
   int gc0;
+  int base;   // first column of the vector load
+  bool vec;   // one aligned 8/16-byte load (possibly of the mirrored group, see rev)
+  bool rev;   // the group lies entirely in the symmetric extension: mirrored aligned group, reversed
+  bool dead;  // no output of this wave depends on these columns: nothing is loaded
+  bool own;   // this lane accounts these pixels in the fg/bg statistic
+  int rc[4];  // reflected column per element (scalar path)
 };
 
-__device__ __forceinline__ MarchCol march_col(int gc0, int W, bool lane_owns) {
+__device__ __forceinline__ MarchCol march_col(int gc0, int W, int ld, int w_out, bool lane_owns) {
   MarchCol c;
   c.gc0 = gc0;
-  c.vec = (W & 3) == 0;
+  c.own = lane_owns;
+  c.dead = gc0 > 2 * w_out - 1;  // coefficient j needs input columns 2j-4 .. 2j+1 only
   c.rev = false;
   c.base = gc0;
-  if (gc0 < 0) { c.base = -gc0 - 4; c.rev = true; }
-  else if (gc0 >= W) { c.base = 2 * W - 4 - gc0; c.rev = true; }
-  if (c.base < 0 || c.base + 3 >= W) c.base = 0;  // far outside: outputs of this lane are unused
-  c.own = lane_owns && gc0 >= 0 && gc0 < W;
+  const bool aligned = (ld & 3) == 0;
+  c.vec = aligned && gc0 >= 0 && gc0 + 3 < W;
+  if (!c.vec && aligned && (W & 3) == 0) {
+    // W % 4 == 0: a group never straddles the edge, the mirrored group is aligned as well
+    if (gc0 + 3 < 0 && -gc0 - 1 < W) { c.base = -gc0 - 4; c.rev = true; c.vec = true; }
+    else if (gc0 >= W && 2 * W - 4 - gc0 >= 0) { c.base = 2 * W - 4 - gc0; c.rev = true; c.vec = true; }
+  }
+  if (c.dead) { c.base = 0; c.rev = false; }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c.rc[e] = reflect_idx(gc0 + e, W);
   return c;
 }
 
+// Issue the loads of one row (prefetch).  all_vec (wave-uniform): every lane of the wave is either
+// vector-loadable or dead, so the load is unconditional and branch-free (a per-lane branch around
+// a prefetch load makes the compiler drain it before the other path may write the registers).
 template <int IN_KIND>
-__device__ __forceinline__ MarchRaw<IN_KIND> march_issue(const void* src, int W, int H, int gr_raw,
-                                                         const MarchCol& c) {
-  MarchRaw<IN_KIND> r;
-  r.u = make_uint2(0u, 0u);
+__device__ __forceinline__ MarchRaw march_issue(const void* src, int ld, int H, int gr_raw, const MarchCol& c,
+                                                bool all_vec) {
+  MarchRaw r;
+  const long long row = (long long)reflect_idx(gr_raw, H) * ld;
+  if (all_vec) {
+    if (IN_KIND == 0) {
+      const uint2 u = *(const uint2*)((const uint16_t*)src + row + c.base);
+      r.f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+    } else {
+      r.f = *(const float4*)((const float*)src + row + c.base);
+    }
+    return r;
+  }
   r.f = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c.vec) {
-    const long long off = (long long)reflect_idx(gr_raw, H) * W + c.base;
-    if (IN_KIND == 0) r.u = *(const uint2*)((const uint16_t*)src + off);
-    else r.f = *(const float4*)((const float*)src + off);
+  if (c.dead) return r;
+  if (IN_KIND == 0) {
+    const uint16_t* p = (const uint16_t*)src + row;
+    if (c.vec) {
+      const uint2 u = *(const uint2*)(p + c.base);
+      r.f.x = __uint_as_float(u.x);
+      r.f.y = __uint_as_float(u.y);
+    } else {
+      const unsigned u0 = p[c.rc[0]], u1 = p[c.rc[1]], u2 = p[c.rc[2]], u3 = p[c.rc[3]];
+      r.f.x = __uint_as_float(u0 | (u1 << 16));
+      r.f.y = __uint_as_float(u2 | (u3 << 16));
+    }
+  } else {
+    const float* p = (const float*)src + row;
+    if (c.vec) r.f = *(const float4*)(p + c.base);
+    else r.f = make_float4(p[c.rc[0]], p[c.rc[1]], p[c.rc[2]], p[c.rc[3]]);
   }
   return r;
 }
 
-// convert a raw row: statistic on owned pixels, then log(1 + x)
+// convert a raw row: statistic on owned pixels and log(1 + x) for pixel planes; identity for aa_{l-1}
 template <int IN_KIND>
-__device__ __forceinline__ void march_consume(const Fwd1Args& a, const void* src, const MarchRaw<IN_KIND>& r,
-                                              int gr_raw, const MarchCol& c, bool row_in_seg,
-                                              MarchStats<IN_KIND>& st, float (&x)[4]) {
-  const bool own_row = row_in_seg && gr_raw >= 0 && gr_raw < a.H;
-  if (c.vec) {
-    float v[4];
-    if (IN_KIND == 0) {
-      v[0] = (float)(r.u.x & 0xFFFFu); v[1] = (float)(r.u.x >> 16);
-      v[2] = (float)(r.u.y & 0xFFFFu); v[3] = (float)(r.u.y >> 16);
-    } else {
-      v[0] = r.f.x; v[1] = r.f.y; v[2] = r.f.z; v[3] = r.f.w;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float f = c.rev ? v[3 - e] : v[e];
-      if (own_row && c.own) st.add(f, a.fg_cutoff);
-      x[e] = __logf(1.0f + f);
-    }
+__device__ __forceinline__ void march_consume(const Fwd1Args& a, const MarchRaw& r, int gr_raw, const MarchCol& c,
+                                              bool row_in_seg, MarchStats<IN_KIND>& st, float (&x)[4]) {
+  float v[4];
+  if (IN_KIND == 0) {
+    const unsigned u0 = __float_as_uint(r.f.x), u1 = __float_as_uint(r.f.y);
+    v[0] = (float)(u0 & 0xFFFFu); v[1] = (float)(u0 >> 16);
+    v[2] = (float)(u1 & 0xFFFFu); v[3] = (float)(u1 >> 16);
   } else {
-    const int gr = reflect_idx(gr_raw, a.H);
+    v[0] = r.f.x; v[1] = r.f.y; v[2] = r.f.z; v[3] = r.f.w;
+  }
+  if (c.vec && c.rev) {  // mirrored group: reverse the element order
+    const float t0 = v[0], t1 = v[1];
+    v[0] = v[3]; v[1] = v[2]; v[2] = t1; v[3] = t0;
+  }
+  if (IN_KIND == 2) {
+    x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
+    return;
+  }
+  const bool own_row = row_in_seg && c.own && gr_raw >= 0 && gr_raw < a.H;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int gc_raw = c.gc0 + e;
-      const int gc = reflect_idx(gc_raw, a.W);
-      const long long off = (long long)gr * a.W + gc;
-      const float f = (IN_KIND == 0) ? (float)((const uint16_t*)src)[off] : ((const float*)src)[off];
-      if (own_row && c.own && gc_raw >= 0 && gc_raw < a.W) st.add(f, a.fg_cutoff);
-      x[e] = __logf(1.0f + f);
-    }
+  for (int e = 0; e < 4; ++e) {
+    if (own_row && c.gc0 + e >= 0 && c.gc0 + e < a.W) st.add(v[e], a.fg_cutoff);
+    x[e] = __logf(1.0f + v[e]);
   }
 }
 
-// IN_KIND: 0 = uint16 pixels, 1 = float32 pixels
+// IN_KIND: 0 = uint16 pixels (log + statistic fused), 1 = float32 pixels (same), 2 = float32 aa_{l-1}
 template <int IN_KIND>
-__global__ __launch_bounds__(256) void k_fwd1_march(Fwd1Args a) {
+__global__ __launch_bounds__(256) void k_fwd_march(Fwd1Args a) {
   __shared__ __attribute__((aligned(16))) float s_row[4][2][2][kMarchCols / 2];  // [wave][lo|hi][parity][col/2]
   constexpr float LO[6] = DSX_DEC_LO;
   constexpr float HI[6] = DSX_DEC_HI;
@@ -399,24 +424,26 @@ __global__ __launch_bounds__(256) void k_fwd1_march(Fwd1Args a) {
   if (i_begin >= i_end) return;
   const int j0 = kMarchOut * strip;
   // lane 0 re-reads the last 4 columns of the previous strip and does not account them
-  const MarchCol col = march_col(2 * j0 - 4 + 4 * lane, a.W, lane >= 1);
-  const void* src = (IN_KIND == 0) ? (const void*)((const uint16_t*)a.in + plane * a.in_plane_stride)
-                                   : (const void*)((const float*)a.in + plane * a.in_plane_stride);
+  const MarchCol col = march_col(2 * j0 - 4 + 4 * lane, a.W, a.ldin, a.w, lane >= 1);
+  const bool all_vec = __all(col.vec || (col.dead && a.W >= 4 && (a.ldin & 3) == 0)) != 0;
+  const void* src;
+  if (IN_KIND == 0) src = (const uint16_t*)a.in + plane * a.in_plane_stride;
+  else if (IN_KIND == 1) src = (const float*)a.in + plane * a.in_plane_stride;
+  else src = a.ws + plane * a.ws_plane_stride + a.in_off;
   float* aa = a.ws + plane * a.ws_plane_stride + a.aa_off;
   float* da = a.ws + plane * a.ws_plane_stride + a.da_off;
   float2* sE[2] = {(float2*)s_row[wave][0][0], (float2*)s_row[wave][1][0]};
   float2* sO[2] = {(float2*)s_row[wave][0][1], (float2*)s_row[wave][1][1]};
 
   MarchStats<IN_KIND> st;
-  float win[6][4];  // sliding window of log(1 + pixel): rows 2i-4 .. 2i+1, this lane's 4 columns
+  float win[6][4];  // sliding window: rows 2i-4 .. 2i+1 of this lane's 4 columns
   // prologue: rows 2 i_begin - 4 .. 2 i_begin - 1 (owned by the previous segment / outside the plane)
   {
-    MarchRaw<IN_KIND> pr[4];
+    MarchRaw pr[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pr[r] = march_issue<IN_KIND>(src, a.W, a.H, 2 * i_begin - 4 + r, col);
+    for (int r = 0; r < 4; ++r) pr[r] = march_issue<IN_KIND>(src, a.ldin, a.H, 2 * i_begin - 4 + r, col, all_vec);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      march_consume<IN_KIND>(a, src, pr[r], 2 * i_begin - 4 + r, col, false, st, win[r]);
+    for (int r = 0; r < 4; ++r) march_consume<IN_KIND>(a, pr[r], 2 * i_begin - 4 + r, col, false, st, win[r]);
   }
 
   float qmin = __builtin_huge_valf(), qmax = 0.f;
@@ -424,10 +451,10 @@ __global__ __launch_bounds__(256) void k_fwd1_march(Fwd1Args a) {
   const bool out_lane = lane < kMarchOut / 2;
 
   // One output row i: the raw rows 2i, 2i+1 become window slots (r4, r5); r0..r5 = oldest..newest.
-  auto step = [&](int i, const MarchRaw<IN_KIND>& raw0, const MarchRaw<IN_KIND>& raw1, float (&r0)[4],
-                  float (&r1)[4], float (&r2)[4], float (&r3)[4], float (&r4)[4], float (&r5)[4]) {
-    march_consume<IN_KIND>(a, src, raw0, 2 * i, col, true, st, r4);
-    march_consume<IN_KIND>(a, src, raw1, 2 * i + 1, col, true, st, r5);
+  auto step = [&](int i, const MarchRaw& raw0, const MarchRaw& raw1, float (&r0)[4], float (&r1)[4],
+                  float (&r2)[4], float (&r3)[4], float (&r4)[4], float (&r5)[4]) {
+    march_consume<IN_KIND>(a, raw0, 2 * i, col, true, st, r4);
+    march_consume<IN_KIND>(a, raw1, 2 * i + 1, col, true, st, r5);
     // axis 0: out = sum_k f[k] * x[2i + 1 - k] = sum_k f[k] * r(5 - k)
     float lo[4], hi[4];
 #pragma unroll
@@ -484,16 +511,16 @@ __global__ __launch_bounds__(256) void k_fwd1_march(Fwd1Args a) {
 
   // software prefetch: the 6 rows of the NEXT group of 3 output rows are in flight while the
   // current group is filtered (the symmetric extension keeps every prefetched address valid)
-  MarchRaw<IN_KIND> nxt[6];
+  MarchRaw nxt[6];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND>(src, a.W, a.H, 2 * i_begin + r, col);
+  for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND>(src, a.ldin, a.H, 2 * i_begin + r, col, all_vec);
   for (int i = i_begin; i < i_end; i += 3) {
-    MarchRaw<IN_KIND> cur[6];
+    MarchRaw cur[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) cur[r] = nxt[r];
     if (i + 3 < i_end) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND>(src, a.W, a.H, 2 * (i + 3) + r, col);
+      for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND>(src, a.ldin, a.H, 2 * (i + 3) + r, col, all_vec);
     }
     step(i, cur[0], cur[1], win[0], win[1], win[2], win[3], win[4], win[5]);
     if (i + 1 < i_end) step(i + 1, cur[2], cur[3], win[2], win[3], win[4], win[5], win[0], win[1]);
@@ -502,28 +529,30 @@ __global__ __launch_bounds__(256) void k_fwd1_march(Fwd1Args a) {
 
   qmin = wave_min_f32(qmin);
   qmax = wave_max_f32(qmax);
-  double s_all, s_fg;
-  if (IN_KIND == 0) {
-    s_all = (double)st.isum_all;
-    s_fg = (double)st.isum_fg;
-  } else {
-    s_all = st.fsum_all;
-    s_fg = st.fsum_fg;
+  if (lane == 0 && qmin <= qmax) {
+    unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
+    atomicMax(&mm[0], ~as_u32(qmin));
+    atomicMax(&mm[1], as_u32(qmax));
   }
-  s_all = wave_sum_f64(s_all);
-  s_fg = wave_sum_f64(s_fg);
-  const unsigned cnt = __reduce_add_sync(~0ull, st.cnt);
-  if (lane == 0) {
-    unsigned* mm = a.minmax + (long long)plane * a.L * 2;
-    if (qmin <= qmax) {
-      atomicMax(&mm[0], ~as_u32(qmin));
-      atomicMax(&mm[1], as_u32(qmax));
+  if (IN_KIND != 2) {
+    double s_all, s_fg;
+    if (IN_KIND == 0) {
+      s_all = (double)st.isum_all;
+      s_fg = (double)st.isum_fg;
+    } else {
+      s_all = st.fsum_all;
+      s_fg = st.fsum_fg;
     }
-    PlaneStats* ps = a.stats + plane;
-    if (s_all != 0.0) atomicAdd(&ps->sum_all, s_all);
-    if (cnt != 0) {
-      atomicAdd(&ps->sum_fg, s_fg);
-      atomicAdd(&ps->cnt_fg, (unsigned long long)cnt);
+    s_all = wave_sum_f64(s_all);
+    s_fg = wave_sum_f64(s_fg);
+    const unsigned cnt = __reduce_add_sync(~0ull, st.cnt);
+    if (lane == 0) {
+      PlaneStats* ps = a.stats + plane;
+      if (s_all != 0.0) atomicAdd(&ps->sum_all, s_all);
+      if (cnt != 0) {
+        atomicAdd(&ps->sum_fg, s_fg);
+        atomicAdd(&ps->cnt_fg, (unsigned long long)cnt);
+      }
     }
   }
 }
@@ -820,21 +849,22 @@ __device__ __forceinline__ unsigned bisect_pk16(const unsigned (&x)[E], unsigned
 // footprint (5 M complex per block) admits that many blocks per CU anyway.
 template <int CPL>
 constexpr int row_waves_per_simd() {
-  return CPL <= 10 ? 4 : (CPL <= 18 ? 3 : 1);
+  return CPL <= 18 ? 4 : 1;
 }
+constexpr int kRowMaxWaves = 8;  // waves (row pairs) per block; they share one twiddle table
 
 // One wave per pair of rows.  CPL = complex values per lane = ceil(M / 64).
 template <int CPL>
-__global__ __launch_bounds__(256, row_waves_per_simd<CPL>()) void k_rowfilter(RowArgs a) {
+__global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void k_rowfilter(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.M, N = a.w, K = a.K;
   float2* s_tw = dsx_smem;
   float2* buf = dsx_smem + (long long)M * (1 + wave);
-  for (int i = tid; i < M; i += 256) s_tw[i] = a.tw[i];
+  for (int i = tid; i < M; i += blockDim.x) s_tw[i] = a.tw[i];
   __syncthreads();  // the only block-wide barrier: afterwards every wave works on its own rows
 
-  const int pair = blockIdx.x * 4 + wave;
+  const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
   const int npairs = (a.h + 1) >> 1;
   if (pair >= npairs) return;
   const int plane = blockIdx.y;
@@ -879,6 +909,10 @@ __global__ __launch_bounds__(256, row_waves_per_simd<CPL>()) void k_rowfilter(Ro
   // ---- exact row medians (np.median, filtering.py:201) ------------------------------------------
   // k-th smallest key by bisection, 16 bits at a time: first the high half over all elements, then
   // the low half over the elements that share the selected high half.
+  float meda = 0.f, medb = 0.f;
+  // the medians only enter through the masked positions: skip them for a mask-free pair of rows
+  const bool any_mask = __ballot((maska | maskb) != 0ull) != 0ull;
+  if (any_mask) {
   const unsigned k1 = (unsigned)(N - 1) >> 1;
   const unsigned rhi = bisect_pk16<E>(hs, k1, k1);
   unsigned below = __reduce_add_sync(~0ull, count_below_pk16<E>(hs, rhi ^ 0x80008000u));
@@ -894,7 +928,8 @@ __global__ __launch_bounds__(256, row_waves_per_simd<CPL>()) void k_rowfilter(Ro
   const unsigned rlo = bisect_pk16<E>(lsel, k1 - (below & 0xFFFFu), k1 - (below >> 16));
   const unsigned keya = ((rhi & 0xFFFFu) << 16) | (rlo & 0xFFFFu);
   const unsigned keyb = (rhi & 0xFFFF0000u) | (rlo >> 16);
-  float meda = key_f32(keya), medb = key_f32(keyb);
+  meda = key_f32(keya);
+  medb = key_f32(keyb);
   if ((N & 1) == 0) {
     // second middle order statistic: the smallest key above the first one unless the first is tied
     unsigned c = 0, mna = 0xFFFFFFFFu, mnb = 0xFFFFFFFFu;
@@ -924,6 +959,7 @@ __global__ __launch_bounds__(256, row_waves_per_simd<CPL>()) void k_rowfilter(Ro
     meda = 0.5f * (meda + v2a);
     medb = 0.5f * (medb + v2b);
   }
+  }  // any_mask
   // The medians are wave-uniform (SGPR); ROCm 7.2's instruction selection crashes when they flow
   // into the selects / LDS stores below, so pin them into VGPRs.
   asm volatile("" : "+v"(meda), "+v"(medb));
@@ -1120,6 +1156,9 @@ struct FinalArgs {
   const float* dark;
   int dark_ld;
   int nstrips, nseg, rows_per_seg;  // segments in coefficient rows p
+  float* ws_out;      // MODE 2 (pyramid level): c_{l-1} destination = ws_out + plane stride + out_off
+  long long out_off;
+  int ldout;
 };
 
 struct FinalRawC {  // raw coefficients q .. q+3 of one row of c and Delta
@@ -1169,9 +1208,10 @@ __device__ __forceinline__ float final_px(const FinalArgs& a, float c0, float x,
   return v;
 }
 
-// IN_KIND: 0 = uint16 pixels, 1 = float32 pixels
+// IN_KIND: 0 = last level, uint16 pixels; 1 = last level, float32 pixels;
+//          2 = pyramid level: writes c_{l-1} (float32, hout x wout, pitch ldout) into the workspace
 template <int IN_KIND>
-__global__ __launch_bounds__(256) void k_final_march(FinalArgs a) {
+__global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
   constexpr float RL[6] = DSX_REC_LO;
   constexpr float RH[6] = DSX_REC_HI;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1191,8 +1231,9 @@ __global__ __launch_bounds__(256) void k_final_march(FinalArgs a) {
   const bool pyr = a.has_pyr != 0;
   const bool has_c = pyr && a.has_c;
   const bool vec_c = q + 3 < a.wc;
-  const bool vec_in = ((a.W & 3) == 0) && (x0 + 3 < a.W);
-  const bool vec_out = ((a.wout & 3) == 0) && (x0 + 3 < a.wout);
+  const bool vec_in = (IN_KIND != 2) && ((a.W & 3) == 0) && (x0 + 3 < a.W);
+  const int out_pitch = (IN_KIND == 2) ? a.ldout : a.wout;
+  const bool vec_out = ((out_pitch & 3) == 0) && (x0 + 3 < a.wout);
   const long long img_plane = plane * a.img_plane_stride;
 
   auto issue_c = [&](int p) {
@@ -1205,7 +1246,7 @@ __global__ __launch_bounds__(256) void k_final_march(FinalArgs a) {
     FinalRawI<IN_KIND> r;
     r.u = make_uint2(0u, 0u);
     r.f = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (vec_in) {
+    if (IN_KIND != 2 && vec_in) {
       const long long off = img_plane + (long long)min(gy, a.H - 1) * a.W + x0;
       if (IN_KIND == 0) r.u = *(const uint2*)((const uint16_t*)a.img + off);
       else r.f = *(const float4*)((const float*)a.img + off);
@@ -1224,6 +1265,17 @@ __global__ __launch_bounds__(256) void k_final_march(FinalArgs a) {
 
   auto emit_row = [&](int gy, const FinalRawI<IN_KIND>& raw, const float (&c0)[4]) {
     if (gy >= a.hout) return;
+    if (IN_KIND == 2) {
+      float* dst = a.ws_out + plane * a.ws_plane_stride + a.out_off + (long long)gy * a.ldout + x0;
+      if (vec_out) {
+        *(float4*)dst = make_float4(c0[0], c0[1], c0[2], c0[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (x0 + e < a.wout) dst[e] = c0[e];
+      }
+      return;
+    }
     float px[4];
     if (vec_in) {
       if (IN_KIND == 0) {
