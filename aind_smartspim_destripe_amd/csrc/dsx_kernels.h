@@ -319,6 +319,7 @@ struct MarchCol {
   bool rev;   // the group lies entirely in the symmetric extension: mirrored aligned group, reversed
   bool dead;  // no output of this wave depends on these columns: nothing is loaded
   bool own;   // this lane accounts these pixels in the fg/bg statistic
+  unsigned own_mask[2];  // uint16 planes: AND masks of the owned elements {px0|px1<<16, px2|px3<<16}
   int rc[4];  // reflected column per element (scalar path)
 };
 
@@ -337,20 +338,23 @@ __device__ __forceinline__ MarchCol march_col(int gc0, int W, int ld, int w_out,
     else if (gc0 >= W && 2 * W - 4 - gc0 >= 0) { c.base = 2 * W - 4 - gc0; c.rev = true; c.vec = true; }
   }
   if (c.dead) { c.base = 0; c.rev = false; }
+  c.own_mask[0] = c.own_mask[1] = 0u;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) c.rc[e] = reflect_idx(gc0 + e, W);
+  for (int e = 0; e < 4; ++e) {
+    c.rc[e] = reflect_idx(gc0 + e, W);
+    if (lane_owns && gc0 + e >= 0 && gc0 + e < W) c.own_mask[e >> 1] |= (e & 1) ? 0xFFFF0000u : 0x0000FFFFu;
+  }
   return c;
 }
 
 // Issue the loads of one row (prefetch).  all_vec (wave-uniform): every lane of the wave is either
 // vector-loadable or dead, so the load is unconditional and branch-free (a per-lane branch around
 // a prefetch load makes the compiler drain it before the other path may write the registers).
-template <int IN_KIND>
-__device__ __forceinline__ MarchRaw march_issue(const void* src, int ld, int H, int gr_raw, const MarchCol& c,
-                                                bool all_vec) {
+template <int IN_KIND, bool FAST>
+__device__ __forceinline__ MarchRaw march_issue(const void* src, int ld, int H, int gr_raw, const MarchCol& c) {
   MarchRaw r;
   const long long row = (long long)reflect_idx(gr_raw, H) * ld;
-  if (all_vec) {
+  if (FAST) {  // every lane of the wave is vector-loadable (or dead, with a valid dummy address)
     if (IN_KIND == 0) {
       const uint2 u = *(const uint2*)((const uint16_t*)src + row + c.base);
       r.f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
@@ -380,19 +384,41 @@ __device__ __forceinline__ MarchRaw march_issue(const void* src, int ld, int H, 
   return r;
 }
 
-// convert a raw row: statistic on owned pixels and log(1 + x) for pixel planes; identity for aa_{l-1}
+// Convert a raw row.  Pixel planes: fg/bg statistic on owned pixels, then log2(1 + x) with the bare
+// v_log_f32 (inputs are >= 1; the ln 2 factor is folded into the axis-0 filter taps).  aa_{l-1}: identity.
 template <int IN_KIND>
 __device__ __forceinline__ void march_consume(const Fwd1Args& a, const MarchRaw& r, int gr_raw, const MarchCol& c,
-                                              bool row_in_seg, MarchStats<IN_KIND>& st, float (&x)[4]) {
-  float v[4];
+                                              bool row_in_seg, bool any_rev, MarchStats<IN_KIND>& st,
+                                              float (&x)[4]) {
   if (IN_KIND == 0) {
-    const unsigned u0 = __float_as_uint(r.f.x), u1 = __float_as_uint(r.f.y);
-    v[0] = (float)(u0 & 0xFFFFu); v[1] = (float)(u0 >> 16);
-    v[2] = (float)(u1 & 0xFFFFu); v[3] = (float)(u1 >> 16);
-  } else {
-    v[0] = r.f.x; v[1] = r.f.y; v[2] = r.f.z; v[3] = r.f.w;
+    unsigned u0 = __float_as_uint(r.f.x), u1 = __float_as_uint(r.f.y);
+    if (any_rev && c.rev) {  // mirrored group: reverse the four 16-bit elements (edge strips only)
+      const unsigned t = u0;
+      u0 = (u1 >> 16) | (u1 << 16);
+      u1 = (t >> 16) | (t << 16);
+    }
+    if (row_in_seg && gr_raw >= 0 && gr_raw < a.H) {  // wave-uniform: this row is accounted by this segment
+      // ownership per element as AND masks (zeroed pixels add nothing and are below the cut-off)
+      const unsigned o0 = u0 & c.own_mask[0], o1 = u1 & c.own_mask[1];
+      // sum of the four pixels by two SADs against zero; foreground pixels (>= 384) are rare: a
+      // packed max decides whether the per-pixel path is needed at all
+      st.isum_all = __builtin_amdgcn_sad_u16(o1, 0u, __builtin_amdgcn_sad_u16(o0, 0u, st.isum_all));
+      const unsigned m = max(max(o0 & 0xFFFFu, o0 >> 16), max(o1 & 0xFFFFu, o1 >> 16));
+      if ((float)m >= a.fg_cutoff) {
+        const unsigned px[4] = {o0 & 0xFFFFu, o0 >> 16, o1 & 0xFFFFu, o1 >> 16};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((float)px[e] >= a.fg_cutoff) { st.isum_fg += px[e]; st.cnt++; }
+      }
+    }
+    x[0] = __builtin_amdgcn_logf(1.0f + (float)(u0 & 0xFFFFu));
+    x[1] = __builtin_amdgcn_logf(1.0f + (float)(u0 >> 16));
+    x[2] = __builtin_amdgcn_logf(1.0f + (float)(u1 & 0xFFFFu));
+    x[3] = __builtin_amdgcn_logf(1.0f + (float)(u1 >> 16));
+    return;
   }
-  if (c.vec && c.rev) {  // mirrored group: reverse the element order
+  float v[4] = {r.f.x, r.f.y, r.f.z, r.f.w};
+  if (any_rev && c.vec && c.rev) {
     const float t0 = v[0], t1 = v[1];
     v[0] = v[3]; v[1] = v[2]; v[2] = t1; v[3] = t0;
   }
@@ -404,28 +430,26 @@ __device__ __forceinline__ void march_consume(const Fwd1Args& a, const MarchRaw&
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (own_row && c.gc0 + e >= 0 && c.gc0 + e < a.W) st.add(v[e], a.fg_cutoff);
-    x[e] = __logf(1.0f + v[e]);
+    x[e] = __builtin_amdgcn_logf(1.0f + v[e]);
   }
 }
 
-// IN_KIND: 0 = uint16 pixels (log + statistic fused), 1 = float32 pixels (same), 2 = float32 aa_{l-1}
-template <int IN_KIND>
-__global__ __launch_bounds__(256) void k_fwd_march(Fwd1Args a) {
-  __shared__ __attribute__((aligned(16))) float s_row[4][2][2][kMarchCols / 2];  // [wave][lo|hi][parity][col/2]
+// Body of k_fwd_march for one wave.  FAST: every lane's column group is vector-loadable, the loads
+// are unconditional (two instantiations instead of one: if the scalar path shared the registers of
+// the prefetch loads the compiler would drain vmcnt before every one of them).
+template <int IN_KIND, bool FAST>
+__device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)[2][2][kMarchCols / 2],
+                                               int lane, int wave, int strip, int seg, int plane,
+                                               const MarchCol& col, bool any_rev) {
   constexpr float LO[6] = DSX_DEC_LO;
   constexpr float HI[6] = DSX_DEC_HI;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = blockIdx.x * 4 + wave;
-  if (item >= a.nstrips * a.nseg) return;
-  const int strip = item % a.nstrips, seg = item / a.nstrips;
-  const int plane = blockIdx.y;
+  // pixel planes enter as log2(1 + x): the axis-0 taps carry the factor ln 2
+  constexpr float KS = (IN_KIND == 2) ? 1.0f : 0.69314718055994530942f;
+  constexpr float LOV[6] = {LO[0] * KS, LO[1] * KS, LO[2] * KS, LO[3] * KS, LO[4] * KS, LO[5] * KS};
+  constexpr float HIV[6] = {HI[0] * KS, HI[1] * KS, HI[2] * KS, HI[3] * KS, HI[4] * KS, HI[5] * KS};
   const int i_begin = seg * a.rows_per_seg;
   const int i_end = min(a.h, i_begin + a.rows_per_seg);
-  if (i_begin >= i_end) return;
   const int j0 = kMarchOut * strip;
-  // lane 0 re-reads the last 4 columns of the previous strip and does not account them
-  const MarchCol col = march_col(2 * j0 - 4 + 4 * lane, a.W, a.ldin, a.w, lane >= 1);
-  const bool all_vec = __all(col.vec || (col.dead && a.W >= 4 && (a.ldin & 3) == 0)) != 0;
   const void* src;
   if (IN_KIND == 0) src = (const uint16_t*)a.in + plane * a.in_plane_stride;
   else if (IN_KIND == 1) src = (const float*)a.in + plane * a.in_plane_stride;
@@ -441,9 +465,9 @@ __global__ __launch_bounds__(256) void k_fwd_march(Fwd1Args a) {
   {
     MarchRaw pr[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pr[r] = march_issue<IN_KIND>(src, a.ldin, a.H, 2 * i_begin - 4 + r, col, all_vec);
+    for (int r = 0; r < 4; ++r) pr[r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * i_begin - 4 + r, col);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) march_consume<IN_KIND>(a, pr[r], 2 * i_begin - 4 + r, col, false, st, win[r]);
+    for (int r = 0; r < 4; ++r) march_consume<IN_KIND>(a, pr[r], 2 * i_begin - 4 + r, col, false, any_rev, st, win[r]);
   }
 
   float qmin = __builtin_huge_valf(), qmax = 0.f;
@@ -453,19 +477,19 @@ __global__ __launch_bounds__(256) void k_fwd_march(Fwd1Args a) {
   // One output row i: the raw rows 2i, 2i+1 become window slots (r4, r5); r0..r5 = oldest..newest.
   auto step = [&](int i, const MarchRaw& raw0, const MarchRaw& raw1, float (&r0)[4], float (&r1)[4],
                   float (&r2)[4], float (&r3)[4], float (&r4)[4], float (&r5)[4]) {
-    march_consume<IN_KIND>(a, raw0, 2 * i, col, true, st, r4);
-    march_consume<IN_KIND>(a, raw1, 2 * i + 1, col, true, st, r5);
+    march_consume<IN_KIND>(a, raw0, 2 * i, col, true, any_rev, st, r4);
+    march_consume<IN_KIND>(a, raw1, 2 * i + 1, col, true, any_rev, st, r5);
     // axis 0: out = sum_k f[k] * x[2i + 1 - k] = sum_k f[k] * r(5 - k)
     float lo[4], hi[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      lo[e] = LO[0] * r5[e];
-      hi[e] = HI[0] * r5[e];
-      lo[e] = fmaf(LO[1], r4[e], lo[e]); hi[e] = fmaf(HI[1], r4[e], hi[e]);
-      lo[e] = fmaf(LO[2], r3[e], lo[e]); hi[e] = fmaf(HI[2], r3[e], hi[e]);
-      lo[e] = fmaf(LO[3], r2[e], lo[e]); hi[e] = fmaf(HI[3], r2[e], hi[e]);
-      lo[e] = fmaf(LO[4], r1[e], lo[e]); hi[e] = fmaf(HI[4], r1[e], hi[e]);
-      lo[e] = fmaf(LO[5], r0[e], lo[e]); hi[e] = fmaf(HI[5], r0[e], hi[e]);
+      lo[e] = LOV[0] * r5[e];
+      hi[e] = HIV[0] * r5[e];
+      lo[e] = fmaf(LOV[1], r4[e], lo[e]); hi[e] = fmaf(HIV[1], r4[e], hi[e]);
+      lo[e] = fmaf(LOV[2], r3[e], lo[e]); hi[e] = fmaf(HIV[2], r3[e], hi[e]);
+      lo[e] = fmaf(LOV[3], r2[e], lo[e]); hi[e] = fmaf(HIV[3], r2[e], hi[e]);
+      lo[e] = fmaf(LOV[4], r1[e], lo[e]); hi[e] = fmaf(HIV[4], r1[e], hi[e]);
+      lo[e] = fmaf(LOV[5], r0[e], lo[e]); hi[e] = fmaf(HIV[5], r0[e], hi[e]);
     }
     sE[0][lane] = make_float2(lo[0], lo[2]);
     sO[0][lane] = make_float2(lo[1], lo[3]);
@@ -513,14 +537,14 @@ __global__ __launch_bounds__(256) void k_fwd_march(Fwd1Args a) {
   // current group is filtered (the symmetric extension keeps every prefetched address valid)
   MarchRaw nxt[6];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND>(src, a.ldin, a.H, 2 * i_begin + r, col, all_vec);
+  for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * i_begin + r, col);
   for (int i = i_begin; i < i_end; i += 3) {
     MarchRaw cur[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) cur[r] = nxt[r];
     if (i + 3 < i_end) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND>(src, a.ldin, a.H, 2 * (i + 3) + r, col, all_vec);
+      for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * (i + 3) + r, col);
     }
     step(i, cur[0], cur[1], win[0], win[1], win[2], win[3], win[4], win[5]);
     if (i + 1 < i_end) step(i + 1, cur[2], cur[3], win[2], win[3], win[4], win[5], win[0], win[1]);
@@ -557,6 +581,25 @@ __global__ __launch_bounds__(256) void k_fwd_march(Fwd1Args a) {
   }
 }
 
+// IN_KIND: 0 = uint16 pixels (log + statistic fused), 1 = float32 pixels (same), 2 = float32 aa_{l-1}
+template <int IN_KIND>
+__global__ __launch_bounds__(256) void k_fwd_march(Fwd1Args a) {
+  __shared__ __attribute__((aligned(16))) float s_row[4][2][2][kMarchCols / 2];  // [wave][lo|hi][parity][col/2]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps row math on the SALU
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= a.nstrips * a.nseg) return;
+  const int strip = item % a.nstrips, seg = item / a.nstrips;
+  const int plane = blockIdx.y;
+  if (seg * a.rows_per_seg >= a.h) return;
+  // lane 0 re-reads the last 4 columns of the previous strip and does not account them
+  const MarchCol col = march_col(2 * kMarchOut * strip - 4 + 4 * lane, a.W, a.ldin, a.w, lane >= 1);
+  const bool all_vec = __all(col.vec || (col.dead && a.W >= 4 && (a.ldin & 3) == 0)) != 0;
+  const bool any_rev = __any(col.rev) != 0;
+  if (all_vec) fwd_march_body<IN_KIND, true>(a, s_row, lane, wave, strip, seg, plane, col, any_rev);
+  else fwd_march_body<IN_KIND, false>(a, s_row, lane, wave, strip, seg, plane, col, any_rev);
+}
+
 // ================================================================================================
 // K2: histogram of q = cH^2, numpy.histogram(bins=256) rule in float32
 // ================================================================================================
@@ -573,7 +616,8 @@ struct HistArgs {
 
 __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
   __shared__ unsigned s_h[256];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform
   const int plane = blockIdx.y;
   const unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
   const float qmin = as_f32(~mm[0]), qmax = as_f32(mm[1]);
@@ -857,7 +901,8 @@ constexpr int kRowMaxWaves = 8;  // waves (row pairs) per block; they share one 
 template <int CPL>
 __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void k_rowfilter(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform
   const int M = a.M, N = a.w, K = a.K;
   float2* s_tw = dsx_smem;
   float2* buf = dsx_smem + (long long)M * (1 + wave);
@@ -1197,8 +1242,9 @@ __device__ __forceinline__ void final_xsynth(float2 lo, float2 hi, float (&o)[4]
   o[3] = fmaf(lo.y, RL[5], fmaf(hi.x, RL[3], hi.y * RL[1]));
 }
 
-__device__ __forceinline__ float final_px(const FinalArgs& a, float c0, float x, int gy, int gx) {
-  float v = fmaf(1.0f + x, __expf(c0), 1.0f);  // exp(log(1 + x) + c0) + 1   (filtering.py:222)
+// c0l = c0 * log2(e) (the factor is folded into the axis-0 synthesis taps of the last level)
+__device__ __forceinline__ float final_px(const FinalArgs& a, float c0l, float x, int gy, int gx) {
+  float v = fmaf(1.0f + x, __builtin_amdgcn_exp2f(c0l), 1.0f);  // exp(log(1 + x) + c0) + 1  (filtering.py:222)
   if (a.flat != nullptr) {                     // flatfield_correction, filtering.py:399-412
     const float d = a.dark[(long long)gy * a.dark_ld + gx];
     v = (v > d) ? (v - d) : 0.f;
@@ -1212,9 +1258,14 @@ __device__ __forceinline__ float final_px(const FinalArgs& a, float c0, float x,
 //          2 = pyramid level: writes c_{l-1} (float32, hout x wout, pitch ldout) into the workspace
 template <int IN_KIND>
 __global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
-  constexpr float RL[6] = DSX_REC_LO;
-  constexpr float RH[6] = DSX_REC_HI;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr float RL0[6] = DSX_REC_LO;
+  constexpr float RH0[6] = DSX_REC_HI;
+  // last level: the result feeds exp2(), so the axis-0 taps carry the factor log2(e)
+  constexpr float KS = (IN_KIND == 2) ? 1.0f : 1.44269504088896340736f;
+  constexpr float RL[6] = {RL0[0] * KS, RL0[1] * KS, RL0[2] * KS, RL0[3] * KS, RL0[4] * KS, RL0[5] * KS};
+  constexpr float RH[6] = {RH0[0] * KS, RH0[1] * KS, RH0[2] * KS, RH0[3] * KS, RH0[4] * KS, RH0[5] * KS};
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps row math on the SALU
   const int item = blockIdx.x * 4 + wave;
   if (item >= a.nstrips * a.nseg) return;
   const int strip = item % a.nstrips, seg = item / a.nstrips;
@@ -1300,7 +1351,7 @@ __global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
     if (a.out_dtype == 0) {
       unsigned u[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) u[e] = (unsigned)(int)fminf(fmaxf(r[e], 0.f), 65535.f);
+      for (int e = 0; e < 4; ++e) u[e] = (unsigned)fminf(r[e], 65535.f);  // float -> uint saturates below at 0
       if (vec_out) {
         *(uint2*)((uint16_t*)a.out + o) = make_uint2(u[0] | (u[1] << 16), u[2] | (u[3] << 16));
       } else {
