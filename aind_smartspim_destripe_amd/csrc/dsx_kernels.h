@@ -616,8 +616,7 @@ struct HistArgs {
 
 __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
   __shared__ unsigned s_h[256];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int plane = blockIdx.y;
   const unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
   const float qmin = as_f32(~mm[0]), qmax = as_f32(mm[1]);
@@ -901,8 +900,7 @@ constexpr int kRowMaxWaves = 8;  // waves (row pairs) per block; they share one 
 template <int CPL>
 __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void k_rowfilter(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.M, N = a.w, K = a.K;
   float2* s_tw = dsx_smem;
   float2* buf = dsx_smem + (long long)M * (1 + wave);
@@ -1254,28 +1252,21 @@ __device__ __forceinline__ float final_px(const FinalArgs& a, float c0l, float x
   return v;
 }
 
-// IN_KIND: 0 = last level, uint16 pixels; 1 = last level, float32 pixels;
-//          2 = pyramid level: writes c_{l-1} (float32, hout x wout, pitch ldout) into the workspace
-template <int IN_KIND>
-__global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
+// Body of k_inv_march for one wave.  FAST: every lane loads its coefficients / pixels with aligned
+// vector loads, unconditionally (row indices are clamped: rows past the end only feed result rows
+// that are never stored) -- see fwd_march_body for why this is a separate instantiation.
+template <int IN_KIND, bool FAST>
+__device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int strip, int seg, int plane) {
   constexpr float RL0[6] = DSX_REC_LO;
   constexpr float RH0[6] = DSX_REC_HI;
   // last level: the result feeds exp2(), so the axis-0 taps carry the factor log2(e)
   constexpr float KS = (IN_KIND == 2) ? 1.0f : 1.44269504088896340736f;
   constexpr float RL[6] = {RL0[0] * KS, RL0[1] * KS, RL0[2] * KS, RL0[3] * KS, RL0[4] * KS, RL0[5] * KS};
   constexpr float RH[6] = {RH0[0] * KS, RH0[1] * KS, RH0[2] * KS, RH0[3] * KS, RH0[4] * KS, RH0[5] * KS};
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps row math on the SALU
-  const int item = blockIdx.x * 4 + wave;
-  if (item >= a.nstrips * a.nseg) return;
-  const int strip = item % a.nstrips, seg = item / a.nstrips;
-  const int plane = blockIdx.y;
   const int np = (a.hout + 1) >> 1;  // coefficient rows that produce result rows
   const int p_begin = seg * a.rows_per_seg;
   const int p_end = min(np, p_begin + a.rows_per_seg);
-  if (p_begin >= p_end) return;
   const int x0 = kMarchCols * strip + 4 * lane;
-  if (x0 >= a.wout) return;
   const int q = x0 >> 1;
   const float* cbase = a.ws + plane * a.ws_plane_stride + a.c_off;
   const float* dbase = a.ws + plane * a.ws_plane_stride + a.d_off;
@@ -1289,6 +1280,17 @@ __global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
 
   auto issue_c = [&](int p) {
     FinalRawC r;
+    if (FAST) {
+      const long long ro = (long long)min(p, a.hc - 1) * a.ldc + q;
+      r.c01 = r.c23 = make_float2(0.f, 0.f);
+      if (has_c) {  // uniform: the coarsest level has no approximation correction
+        r.c01 = *(const float2*)(cbase + ro);
+        r.c23 = *(const float2*)(cbase + ro + 2);
+      }
+      r.d01 = *(const float2*)(dbase + ro);
+      r.d23 = *(const float2*)(dbase + ro + 2);
+      return r;
+    }
     final_coeff_row(a, cbase, p, q, has_c, vec_c, r.c01, r.c23);
     final_coeff_row(a, dbase, p, q, pyr, vec_c, r.d01, r.d23);
     return r;
@@ -1297,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
     FinalRawI<IN_KIND> r;
     r.u = make_uint2(0u, 0u);
     r.f = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (IN_KIND != 2 && vec_in) {
+    if (IN_KIND != 2 && (FAST || vec_in)) {
       const long long off = img_plane + (long long)min(gy, a.H - 1) * a.W + x0;
       if (IN_KIND == 0) r.u = *(const uint2*)((const uint16_t*)a.img + off);
       else r.f = *(const float4*)((const float*)a.img + off);
@@ -1328,7 +1330,7 @@ __global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
       return;
     }
     float px[4];
-    if (vec_in) {
+    if (FAST || vec_in) {
       if (IN_KIND == 0) {
         px[0] = (float)(raw.u.x & 0xFFFFu); px[1] = (float)(raw.u.x >> 16);
         px[2] = (float)(raw.u.y & 0xFFFFu); px[3] = (float)(raw.u.y >> 16);
@@ -1419,6 +1421,25 @@ __global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
     if (p + 1 < p_end) step(p + 1, cc[1], ci[2], ci[3], A[1], A[2], A[0], D[1], D[2], D[0]);
     if (p + 2 < p_end) step(p + 2, cc[2], ci[4], ci[5], A[2], A[0], A[1], D[2], D[0], D[1]);
   }
+}
+
+// IN_KIND: 0 = last level, uint16 pixels; 1 = last level, float32 pixels;
+//          2 = pyramid level: writes c_{l-1} (float32, hout x wout, pitch ldout) into the workspace
+template <int IN_KIND>
+__global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps row math on the SALU
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= a.nstrips * a.nseg) return;
+  const int strip = item % a.nstrips, seg = item / a.nstrips;
+  const int plane = blockIdx.y;
+  if (seg * a.rows_per_seg >= ((a.hout + 1) >> 1)) return;
+  const int x0 = kMarchCols * strip + 4 * lane;
+  if (x0 >= a.wout) return;
+  const bool lane_fast = (a.has_pyr != 0) && ((x0 >> 1) + 3 < a.wc) && ((a.ldc & 1) == 0) &&
+                         (IN_KIND == 2 || (((a.W & 3) == 0) && (x0 + 3 < a.W)));
+  if (__all(lane_fast)) inv_march_body<IN_KIND, true>(a, lane, strip, seg, plane);
+  else inv_march_body<IN_KIND, false>(a, lane, strip, seg, plane);
 }
 
 }  // namespace dsx
