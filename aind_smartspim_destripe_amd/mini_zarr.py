@@ -1,0 +1,151 @@
+"""Minimal Zarr-v2 directory store (read / write) for the chunk map.
+
+Neither ``zarr`` nor ``numcodecs`` is installed in this environment (and blosc / zstd are not
+available offline), so the chunk map carries its own small implementation of the subset it needs:
+C-order arrays, little-endian numeric dtypes, ``compressor`` ``null`` or ``zlib``, ``"."`` or ``"/"``
+chunk-key separators, basic slicing with unit steps.  The reference's production arrays are
+``uint16``, chunks ``(1, 1, 64, 128, 128)``, Blosc-zstd, ``dimension_separator="/"``
+(``zarr_destriper.py:1066-1074``); Blosc chunks are rejected with a clear error.
+"""
+
+import itertools
+import json
+import os
+import zlib
+
+import numpy as np
+
+
+class MiniZarrArray:
+    def __init__(self, path, meta):
+        self.path = str(path)
+        self.shape = tuple(meta["shape"])
+        self.chunks = tuple(meta["chunks"])
+        self.dtype = np.dtype(meta["dtype"])
+        self.fill_value = meta.get("fill_value", 0) or 0
+        self.sep = meta.get("dimension_separator", ".")
+        comp = meta.get("compressor")
+        if comp is None:
+            self.compressor = None
+        elif comp.get("id") == "zlib":
+            self.compressor = ("zlib", int(comp.get("level", 1)))
+        else:
+            raise NotImplementedError(
+                "compressor {!r} is not available offline (only null / zlib)".format(comp.get("id"))
+            )
+        if meta.get("order", "C") != "C" or meta.get("filters"):
+            raise NotImplementedError("only C-order arrays without filters are supported")
+        self.ndim = len(self.shape)
+
+    # -- construction -------------------------------------------------------------------------
+    @classmethod
+    def create(cls, path, shape, chunks, dtype, compressor=None, dimension_separator="/", fill_value=0,
+               overwrite=True):  # fmt: skip
+        os.makedirs(path, exist_ok=True)
+        if not overwrite and os.path.exists(os.path.join(path, ".zarray")):
+            raise FileExistsError(path)
+        comp = None
+        if compressor == "zlib":
+            comp = {"id": "zlib", "level": 1}
+        elif compressor is not None:
+            raise NotImplementedError("only null / zlib compressors")
+        meta = {
+            "zarr_format": 2,
+            "shape": list(shape),
+            "chunks": list(chunks),
+            "dtype": np.dtype(dtype).str,
+            "compressor": comp,
+            "fill_value": fill_value,
+            "order": "C",
+            "filters": None,
+            "dimension_separator": dimension_separator,
+        }
+        with open(os.path.join(path, ".zarray"), "w") as f:
+            json.dump(meta, f)
+        return cls(path, meta)
+
+    @classmethod
+    def open(cls, path):
+        with open(os.path.join(path, ".zarray")) as f:
+            return cls(path, json.load(f))
+
+    # -- chunk io -----------------------------------------------------------------------------
+    def _chunk_path(self, idx):
+        return os.path.join(self.path, self.sep.join(str(i) for i in idx).replace("/", os.sep))
+
+    def _read_chunk(self, idx):
+        p = self._chunk_path(idx)
+        if not os.path.exists(p):
+            return np.full(self.chunks, self.fill_value, dtype=self.dtype)
+        with open(p, "rb") as f:
+            raw = f.read()
+        if self.compressor is not None:
+            raw = zlib.decompress(raw)
+        return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks).copy()
+
+    def _write_chunk(self, idx, block):
+        p = self._chunk_path(idx)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        raw = np.ascontiguousarray(block, dtype=self.dtype).tobytes()
+        if self.compressor is not None:
+            raw = zlib.compress(raw, self.compressor[1])
+        with open(p + ".tmp", "wb") as f:
+            f.write(raw)
+        os.replace(p + ".tmp", p)
+
+    # -- slicing ------------------------------------------------------------------------------
+    def _normalize(self, key):
+        if not isinstance(key, tuple):
+            key = (key,)
+        if any(k is Ellipsis for k in key):
+            i = key.index(Ellipsis)
+            key = key[:i] + (slice(None),) * (self.ndim - len(key) + 1) + key[i + 1 :]
+        key = key + (slice(None),) * (self.ndim - len(key))
+        out, squeeze = [], []
+        for ax, (k, n) in enumerate(zip(key, self.shape)):
+            if isinstance(k, (int, np.integer)):
+                k = int(k) + (n if k < 0 else 0)
+                out.append((k, k + 1))
+                squeeze.append(ax)
+            else:
+                start, stop, step = k.indices(n)
+                if step != 1:
+                    raise NotImplementedError("only unit steps")
+                out.append((start, max(start, stop)))
+        return out, tuple(squeeze)
+
+    def _chunk_ranges(self, bounds):
+        return [range(lo // c, (hi - 1) // c + 1) if hi > lo else range(0) for (lo, hi), c in zip(bounds, self.chunks)]
+
+    def __getitem__(self, key):
+        bounds, squeeze = self._normalize(key)
+        out = np.empty([hi - lo for lo, hi in bounds], dtype=self.dtype)
+        for idx in itertools.product(*self._chunk_ranges(bounds)):
+            chunk = self._read_chunk(idx)
+            src, dst = [], []
+            for (lo, hi), c, i in zip(bounds, self.chunks, idx):
+                a, b = max(lo, i * c), min(hi, (i + 1) * c)
+                src.append(slice(a - i * c, b - i * c))
+                dst.append(slice(a - lo, b - lo))
+            out[tuple(dst)] = chunk[tuple(src)]
+        return out.squeeze(axis=squeeze) if squeeze else out
+
+    def __setitem__(self, key, value):
+        bounds, _ = self._normalize(key)
+        shape = [hi - lo for lo, hi in bounds]
+        # NumPy assignment cast, as zarr does: float -> uint16 truncates (zarr_destriper.py:336)
+        value = np.broadcast_to(np.asarray(value), shape) if np.ndim(value) else np.full(shape, value)
+        value = value.astype(self.dtype, copy=False)
+        for idx in itertools.product(*self._chunk_ranges(bounds)):
+            src, dst, full = [], [], True
+            for (lo, hi), c, i, n in zip(bounds, self.chunks, idx, self.shape):
+                a, b = max(lo, i * c), min(hi, (i + 1) * c)
+                dst.append(slice(a - i * c, b - i * c))
+                src.append(slice(a - lo, b - lo))
+                full = full and (a == i * c) and (b == min((i + 1) * c, n))
+            if full and all(s.stop - s.start == c for s, c in zip(dst, self.chunks)):
+                chunk = value[tuple(src)]
+            else:
+                chunk = self._read_chunk(idx)
+                chunk[tuple(dst)] = value[tuple(src)]
+            self._write_chunk(idx, chunk)
