@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -71,6 +72,7 @@ struct dsx_ctx {
   bool profiling = false;
   std::vector<ProfRec> prof;
   size_t workspace_bytes = 0;
+  int ablate = 0;  // DSX_ABLATE environment variable: row-filter phase ablation, diagnosis only
 };
 
 namespace {
@@ -282,6 +284,7 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
     a.g[0] = (const float2*)(ctx->d_consts + lp.g_off[0]);
     a.g[1] = (const float2*)(ctx->d_consts + lp.g_off[1]);
     a.inv_M = 1.0f / (float)lp.M;
+    a.ablate = ctx->ablate;
     const int npairs = (lp.h + 1) / 2;
     LaunchScope ls(ctx, KC_ROW);
     DSX_HIP(dispatch_rowfilter(a, npairs, nb, s));
@@ -364,6 +367,7 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
   if (e != hipSuccess) { g_init_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return DSX_EHIP; }
   dsx_ctx* c = new dsx_ctx();
   c->device = device;
+  if (const char* ab = getenv("DSX_ABLATE")) c->ablate = atoi(ab);
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->t0);
   if (e == hipSuccess) e = hipEventCreate(&c->t1);

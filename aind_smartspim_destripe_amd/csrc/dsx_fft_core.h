@@ -243,8 +243,10 @@ DSX_HD void dsx_bfly_load(const dsx_c32* buf, int b, int nb, dsx_c32* v) {
 }
 
 // butterfly + twiddles + autosort scatter of butterfly b (sub-transform stride s)
+// unit_tw: last pass of a transform (s * R == M, so p == 0 and every twiddle is 1)
 template <int R>
-DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float inv_s, dsx_c32* v) {
+DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float inv_s, dsx_c32* v,
+                           bool unit_tw = false) {
   const int q = (s == 1) ? 0 : dsx_mod_s(b, s, inv_s);
   const int ps = b - q;
   const int dst = R * b - (R - 1) * q;
@@ -283,16 +285,28 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
         br += sn * v[R - j].x;
         bi += sn * v[R - j].y;
       }
-      buf[dst + s * k] = dsx_mul(dsx_mk(ar + bi, ai - br), tw[ps * k]);                  // A - iB
-      buf[dst + s * (R - k)] = dsx_mul(dsx_mk(ar - bi, ai + br), tw[ps * (R - k)]);      // A + iB
+      if (unit_tw) {
+        buf[dst + s * k] = dsx_mk(ar + bi, ai - br);        // A - iB
+        buf[dst + s * (R - k)] = dsx_mk(ar - bi, ai + br);  // A + iB
+      } else {
+        buf[dst + s * k] = dsx_mul(dsx_mk(ar + bi, ai - br), tw[ps * k]);
+        buf[dst + s * (R - k)] = dsx_mul(dsx_mk(ar - bi, ai + br), tw[ps * (R - k)]);
+      }
     }
   } else {
     dsx_bfly<R>::run(v);
     buf[dst] = v[0];
+    if (unit_tw) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int k = 1; k < R; ++k) buf[dst + s * k] = dsx_mul(v[k], tw[ps * k]);
+      for (int k = 1; k < R; ++k) buf[dst + s * k] = v[k];
+    } else {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (int k = 1; k < R; ++k) buf[dst + s * k] = dsx_mul(v[k], tw[ps * k]);
+    }
   }
 }
 

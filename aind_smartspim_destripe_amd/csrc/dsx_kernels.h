@@ -768,6 +768,7 @@ struct RowArgs {
   const float2* tw;    // [M] exp(-2 pi i t / M)
   const float2* g[2];  // per config: G1[M] then G2[M]
   float inv_M;
+  int ablate;          // diagnosis only (DSX_ABLATE): 1 = no median, 2 = no FFT passes, 4 = no spectral step
 };
 
 __device__ __forceinline__ unsigned f32_key(float v) {
@@ -783,6 +784,7 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int M, i
                                          int lane) {
   constexpr int MAXB = (CPL + R - 1) / R;
   const int nb = M / R;
+  const bool unit_tw = (s * R == M);  // last pass: all twiddles are 1 (wave-uniform)
   float2 v[MAXB][R];
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
@@ -794,7 +796,7 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int M, i
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
     const int b = lane + kWave * i;
-    if (b < nb) dsx_bfly_store<R>(buf, tw, b, s, inv_s, v[i]);
+    if (b < nb) dsx_bfly_store<R>(buf, tw, b, s, inv_s, v[i], unit_tw);
     // keep the unrolled butterflies from being interleaved: their temporaries would all be live
     // at once (215+ VGPRs at 18 values per lane) for no gain -- other waves hide the latency
     __builtin_amdgcn_sched_barrier(0);
@@ -918,35 +920,49 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   float* rowb = rowa + a.ld;
 
   if (a.lvl >= a.lvl_active[cfg]) {  // this config does not filter this level: Delta = 0
-    for (int n = lane; n < N; n += kWave) {
-      rowa[n] = 0.f;
-      if (has_b) rowb[n] = 0.f;
+    for (int n = 4 * lane; n < N; n += 4 * kWave) {
+      *(float4*)(rowa + n) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_b) *(float4*)(rowb + n) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
   }
   const float thr = a.thr[(long long)plane * a.L + a.lvl];
 
   // ---- load both rows; background = masked entries zeroed (filtering.py:195-197) -------------
+  // Element slot e = 4 g + i of a lane is row element n = 256 g + 4 lane + i: one 16-byte load per
+  // group g (rows are 16-byte aligned, pitch a multiple of 4 floats).
   // Order-preserving 32-bit keys, split into packed 16-bit halves {row a | row b << 16}:
   // hs = high halves, ls = low halves, both in signed order (^ 0x8000) for the saturating compare.
-  constexpr int E = CPL;
+  constexpr int G = (CPL + 3) / 4;
+  constexpr int E = 4 * G;
   unsigned hs[E], ls[E];
   unsigned long long maska = 0, maskb = 0;
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int n = lane + kWave * e;
-    unsigned ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;  // padding sorts last
-    if (n < N) {
-      const float va = rowa[n];
-      const float vb = has_b ? rowb[n] : 0.f;
-      const bool ma = fabsf(va) > thr, mb = fabsf(vb) > thr;
-      if (ma) maska |= (1ull << e);
-      if (mb) maskb |= (1ull << e);
-      ka = f32_key(ma ? 0.f : va);
-      kb = f32_key(mb ? 0.f : vb);
+  for (int g = 0; g < G; ++g) {
+    const int nb0 = 256 * g + 4 * lane;
+    float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (nb0 < N) {  // nb0 + 3 < ld: the pitch is N rounded up to a multiple of 4
+      const float4 fa = *(const float4*)(rowa + nb0);
+      va[0] = fa.x; va[1] = fa.y; va[2] = fa.z; va[3] = fa.w;
+      if (has_b) {
+        const float4 fb = *(const float4*)(rowb + nb0);
+        vb[0] = fb.x; vb[1] = fb.y; vb[2] = fb.z; vb[3] = fb.w;
+      }
     }
-    hs[e] = ((ka >> 16) | (kb & 0xFFFF0000u)) ^ 0x80008000u;
-    ls[e] = ((ka & 0xFFFFu) | (kb << 16)) ^ 0x80008000u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = 4 * g + i;
+      unsigned ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;  // padding sorts last
+      if (nb0 + i < N) {
+        const bool ma = fabsf(va[i]) > thr, mb = fabsf(vb[i]) > thr;
+        if (ma) maska |= (1ull << e);
+        if (mb) maskb |= (1ull << e);
+        ka = f32_key(ma ? 0.f : va[i]);
+        kb = f32_key(mb ? 0.f : vb[i]);
+      }
+      hs[e] = ((ka >> 16) | (kb & 0xFFFF0000u)) ^ 0x80008000u;
+      ls[e] = ((ka & 0xFFFFu) | (kb << 16)) ^ 0x80008000u;
+    }
   }
 
   // ---- exact row medians (np.median, filtering.py:201) ------------------------------------------
@@ -955,7 +971,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   float meda = 0.f, medb = 0.f;
   // the medians only enter through the masked positions: skip them for a mask-free pair of rows
   const bool any_mask = __ballot((maska | maskb) != 0ull) != 0ull;
-  if (any_mask) {
+  if (any_mask && !(a.ablate & 1)) {
   const unsigned k1 = (unsigned)(N - 1) >> 1;
   const unsigned rhi = bisect_pk16<E>(hs, k1, k1);
   unsigned below = __reduce_add_sync(~0ull, count_below_pk16<E>(hs, rhi ^ 0x80008000u));
@@ -1010,7 +1026,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   // ---- in-painted rows -> complex buffer u[m] = x[(m - K) mod N], m in [0, N + 2K]; zero above -----
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const int n = lane + kWave * e;
+    const int n = 256 * (e >> 2) + 4 * lane + (e & 3);
     if (n < N) {
       const unsigned h = hs[e] ^ 0x80008000u, l = ls[e] ^ 0x80008000u;
       const float xa = ((maska >> e) & 1ull) ? meda : key_f32((h << 16) | (l & 0xFFFFu));
@@ -1028,12 +1044,12 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   }
   wave_sync();
 
-  fft_run<CPL>(buf, s_tw, a, lane);
+  if (!(a.ablate & 2)) fft_run<CPL>(buf, s_tw, a, lane);
 
   // ---- V[k] = G1[k] U[k] + G2[k] U[M - k], in place on the pair (k, M - k) ---------------------
   // G1 is real and even, G2[M - k] = conj(G2[k]) (both modes, dsx_plan.h).  The result is stored
   // re/im-swapped: the inverse transform runs through the forward passes.
-  {
+  if (!(a.ablate & 4)) {
     const float2* g1 = a.g[cfg];
     const float2* g2 = g1 + M;
     for (int k = lane; 2 * k <= M; k += kWave) {
@@ -1049,16 +1065,24 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
     wave_sync();
   }
 
-  fft_run<CPL>(buf, s_tw, a, lane);
+  if (!(a.ablate & 2)) fft_run<CPL>(buf, s_tw, a, lane);
 
   // ---- buf = swap(M * LP): row a <- .y, row b <- .x ; Delta = -(1 - mask) LP (filtering.py:215-217)
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int n = lane + kWave * e;
-    if (n < N) {
-      const float2 y = buf[K + n];
-      rowa[n] = ((maska >> e) & 1ull) ? 0.f : -y.y * a.inv_M;
-      if (has_b) rowb[n] = ((maskb >> e) & 1ull) ? 0.f : -y.x * a.inv_M;
+  for (int g = 0; g < G; ++g) {
+    const int nb0 = 256 * g + 4 * lane;
+    if (nb0 < N) {
+      float da_[4], db_[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = 4 * g + i;
+        const float2 y = (nb0 + i < N) ? buf[K + nb0 + i] : make_float2(0.f, 0.f);
+        da_[i] = ((maska >> e) & 1ull) ? 0.f : -y.y * a.inv_M;
+        db_[i] = ((maskb >> e) & 1ull) ? 0.f : -y.x * a.inv_M;
+      }
+      // the pitch covers nb0 + 3: pad columns beyond N are never read as data
+      *(float4*)(rowa + nb0) = make_float4(da_[0], da_[1], da_[2], da_[3]);
+      if (has_b) *(float4*)(rowb + nb0) = make_float4(db_[0], db_[1], db_[2], db_[3]);
     }
   }
 }
