@@ -125,6 +125,42 @@ struct dsx_bfly<5> {
 // X[k], X[P-k] = A -/+ iB,  A = x0 + sum_j cos(2 pi jk/P) (x_j + x_{P-j}),  B = sum_j sin(2 pi jk/P) (x_j - x_{P-j})
 DSX_HD constexpr float dsx_root_cos(int P, int j) {
   switch (P) {
+    case 6: {
+      constexpr float t[6] = {1.0f, 0.50000000000000011f, -0.49999999999999978f, -1.0f, -0.50000000000000044f, 0.50000000000000011f};
+      return t[j];
+    }
+    case 8: {
+      constexpr float t[8] = {1.0f, 0.70710678118654757f, 6.123233995736766e-17f, -0.70710678118654746f, -1.0f, -0.70710678118654768f, -1.8369701987210297e-16f, 0.70710678118654735f};
+      return t[j];
+    }
+    case 9: {
+      constexpr float t[9] = {1.0f, 0.76604444311897801f, 0.17364817766693041f, -0.49999999999999978f, -0.93969262078590832f, -0.93969262078590843f, -0.50000000000000044f, 0.17364817766692997f, 0.76604444311897779f};
+      return t[j];
+    }
+    case 10: {
+      constexpr float t[10] = {1.0f, 0.80901699437494745f, 0.30901699437494745f, -0.30901699437494734f, -0.80901699437494734f, -1.0f, -0.80901699437494756f, -0.30901699437494756f, 0.30901699437494723f, 0.80901699437494734f};
+      return t[j];
+    }
+    case 12: {
+      constexpr float t[12] = {1.0f, 0.86602540378443871f, 0.50000000000000011f, 6.123233995736766e-17f, -0.49999999999999978f, -0.86602540378443871f, -1.0f, -0.86602540378443882f, -0.50000000000000044f, -1.8369701987210297e-16f, 0.50000000000000011f, 0.86602540378443837f};
+      return t[j];
+    }
+    case 15: {
+      constexpr float t[15] = {1.0f, 0.91354545764260087f, 0.66913060635885824f, 0.30901699437494745f, -0.10452846326765333f, -0.49999999999999978f, -0.80901699437494734f, -0.97814760073380569f, -0.97814760073380569f, -0.80901699437494756f, -0.50000000000000044f, -0.10452846326765423f, 0.30901699437494723f, 0.66913060635885846f, 0.91354545764260098f};
+      return t[j];
+    }
+    case 16: {
+      constexpr float t[16] = {1.0f, 0.92387953251128674f, 0.70710678118654757f, 0.38268343236508984f, 6.123233995736766e-17f, -0.38268343236508973f, -0.70710678118654746f, -0.92387953251128674f, -1.0f, -0.92387953251128685f, -0.70710678118654768f, -0.38268343236509034f, -1.8369701987210297e-16f, 0.38268343236509f, 0.70710678118654735f, 0.92387953251128652f};
+      return t[j];
+    }
+    case 20: {
+      constexpr float t[20] = {1.0f, 0.95105651629515353f, 0.80901699437494745f, 0.58778525229247314f, 0.30901699437494745f, 6.123233995736766e-17f, -0.30901699437494734f, -0.58778525229247303f, -0.80901699437494734f, -0.95105651629515353f, -1.0f, -0.95105651629515375f, -0.80901699437494756f, -0.58778525229247325f, -0.30901699437494756f, -1.8369701987210297e-16f, 0.30901699437494723f, 0.58778525229247292f, 0.80901699437494734f, 0.95105651629515353f};
+      return t[j];
+    }
+    case 25: {
+      constexpr float t[25] = {1.0f, 0.96858316112863108f, 0.87630668004386358f, 0.72896862742141155f, 0.53582679497899655f, 0.30901699437494745f, 0.062790519529313527f, -0.1873813145857246f, -0.42577929156507272f, -0.63742398974868975f, -0.80901699437494734f, -0.92977648588825135f, -0.99211470131447776f, -0.99211470131447788f, -0.92977648588825146f, -0.80901699437494778f, -0.63742398974868952f, -0.42577929156507216f, -0.18738131458572463f, 0.062790519529312833f, 0.30901699437494723f, 0.53582679497899677f, 0.72896862742141122f, 0.87630668004386314f, 0.96858316112863097f};
+      return t[j];
+    }
     case 7: {
       constexpr float t[7] = {1.0f, 0.62348980185873359f, -0.22252093395631434f, -0.90096886790241903f, -0.90096886790241915f, -0.22252093395631459f, 0.62348980185873337f};
       return t[j];
@@ -150,6 +186,42 @@ DSX_HD constexpr float dsx_root_cos(int P, int j) {
 }
 DSX_HD constexpr float dsx_root_sin(int P, int j) {
   switch (P) {
+    case 6: {
+      constexpr float t[6] = {0.0f, 0.8660254037844386f, 0.86602540378443871f, 1.2246467991473532e-16f, -0.86602540378443837f, -0.8660254037844386f};
+      return t[j];
+    }
+    case 8: {
+      constexpr float t[8] = {0.0f, 0.70710678118654746f, 1.0f, 0.70710678118654757f, 1.2246467991473532e-16f, -0.70710678118654746f, -1.0f, -0.70710678118654768f};
+      return t[j];
+    }
+    case 9: {
+      constexpr float t[9] = {0.0f, 0.64278760968653925f, 0.98480775301220802f, 0.86602540378443871f, 0.34202014332566888f, -0.34202014332566866f, -0.86602540378443837f, -0.98480775301220813f, -0.64278760968653958f};
+      return t[j];
+    }
+    case 10: {
+      constexpr float t[10] = {0.0f, 0.58778525229247314f, 0.95105651629515353f, 0.95105651629515364f, 0.58778525229247325f, 1.2246467991473532e-16f, -0.58778525229247303f, -0.95105651629515353f, -0.95105651629515364f, -0.58778525229247336f};
+      return t[j];
+    }
+    case 12: {
+      constexpr float t[12] = {0.0f, 0.49999999999999994f, 0.8660254037844386f, 1.0f, 0.86602540378443871f, 0.49999999999999994f, 1.2246467991473532e-16f, -0.49999999999999972f, -0.86602540378443837f, -1.0f, -0.8660254037844386f, -0.50000000000000044f};
+      return t[j];
+    }
+    case 15: {
+      constexpr float t[15] = {0.0f, 0.40673664307580015f, 0.74314482547739413f, 0.95105651629515353f, 0.9945218953682734f, 0.86602540378443871f, 0.58778525229247325f, 0.20791169081775931f, -0.20791169081775907f, -0.58778525229247303f, -0.86602540378443837f, -0.99452189536827329f, -0.95105651629515364f, -0.74314482547739402f, -0.40673664307580015f};
+      return t[j];
+    }
+    case 16: {
+      constexpr float t[16] = {0.0f, 0.38268343236508978f, 0.70710678118654746f, 0.92387953251128674f, 1.0f, 0.92387953251128674f, 0.70710678118654757f, 0.38268343236508989f, 1.2246467991473532e-16f, -0.38268343236508967f, -0.70710678118654746f, -0.92387953251128652f, -1.0f, -0.92387953251128663f, -0.70710678118654768f, -0.38268343236509039f};
+      return t[j];
+    }
+    case 20: {
+      constexpr float t[20] = {0.0f, 0.3090169943749474f, 0.58778525229247314f, 0.80901699437494745f, 0.95105651629515353f, 1.0f, 0.95105651629515364f, 0.80901699437494745f, 0.58778525229247325f, 0.30901699437494751f, 1.2246467991473532e-16f, -0.3090169943749469f, -0.58778525229247303f, -0.80901699437494734f, -0.95105651629515353f, -1.0f, -0.95105651629515364f, -0.80901699437494756f, -0.58778525229247336f, -0.30901699437494762f};
+      return t[j];
+    }
+    case 25: {
+      constexpr float t[25] = {0.0f, 0.24868988716485479f, 0.48175367410171532f, 0.68454710592868862f, 0.84432792550201508f, 0.95105651629515353f, 0.99802672842827156f, 0.98228725072868872f, 0.90482705246601947f, 0.77051324277578925f, 0.58778525229247325f, 0.36812455268467814f, 0.12533323356430454f, -0.12533323356430429f, -0.36812455268467792f, -0.58778525229247269f, -0.77051324277578936f, -0.9048270524660198f, -0.98228725072868872f, -0.99802672842827156f, -0.95105651629515364f, -0.84432792550201496f, -0.68454710592868895f, -0.4817536741017161f, -0.24868988716485535f};
+      return t[j];
+    }
     case 7: {
       constexpr float t[7] = {0.0f, 0.7818314824680298f, 0.97492791218182362f, 0.43388373911755823f, -0.43388373911755801f, -0.97492791218182362f, -0.78183148246802991f};
       return t[j];
@@ -233,6 +305,70 @@ struct dsx_bfly<19> {
   DSX_HD static void run(dsx_c32* v) { dsx_bfly_odd<19>(v); }
 };
 
+
+// ---- composite register butterflies R = R1 * R2 (Cooley-Tukey inside the registers) ---------------
+// n = R2 n1 + n2, k = k1 + R1 k2:
+//   X[k1 + R1 k2] = sum_n2 W_R^{n2 k1} (sum_n1 x[R2 n1 + n2] W_R1^{n1 k1}) W_R2^{n2 k2}
+// computed in place; X[k] ends up in v[R2 (k % R1) + k / R1]  (dsx_comp_pos).
+template <int R>
+struct dsx_comp {
+  static constexpr int R1 = 0, R2 = 0;
+};
+#define DSX_COMP(R, A, B)            \
+  template <>                        \
+  struct dsx_comp<R> {               \
+    static constexpr int R1 = A, R2 = B; \
+  };
+DSX_COMP(6, 2, 3)
+DSX_COMP(8, 2, 4)
+DSX_COMP(9, 3, 3)
+DSX_COMP(10, 2, 5)
+DSX_COMP(12, 3, 4)
+DSX_COMP(15, 3, 5)
+DSX_COMP(16, 4, 4)
+DSX_COMP(20, 4, 5)
+DSX_COMP(25, 5, 5)
+#undef DSX_COMP
+
+template <int R>
+DSX_HD constexpr int dsx_comp_pos(int k) {
+  return dsx_comp<R>::R2 * (k % dsx_comp<R>::R1) + k / dsx_comp<R>::R1;
+}
+
+template <int R>
+DSX_HD void dsx_bfly_composite(dsx_c32* v) {
+  constexpr int R1 = dsx_comp<R>::R1, R2 = dsx_comp<R>::R2;
+  // stage 1: R2 butterflies of radix R1 over n1 (stride R2), then the inner twiddles W_R^{n2 k1}
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int n2 = 0; n2 < R2; ++n2) {
+    dsx_c32 t[R1];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int n1 = 0; n1 < R1; ++n1) t[n1] = v[R2 * n1 + n2];
+    dsx_bfly<R1>::run(t);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k1 = 0; k1 < R1; ++k1) {
+      const int e = (n2 * k1) % R;
+      if (e == 0) {
+        v[R2 * k1 + n2] = t[k1];
+      } else {
+        const float c = dsx_root_cos(R, e), sn = -dsx_root_sin(R, e);  // exp(-2 pi i e / R)
+        v[R2 * k1 + n2] = dsx_mk(t[k1].x * c - t[k1].y * sn, t[k1].x * sn + t[k1].y * c);
+      }
+    }
+  }
+  // stage 2: R1 butterflies of radix R2 over n2 (contiguous)
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int k1 = 0; k1 < R1; ++k1) dsx_bfly<R2>::run(v + R2 * k1);
+}
+
 // ---- per-butterfly pieces of a pass (used verbatim by k_rowfilter and by the host unit test) ----
 template <int R>
 DSX_HD void dsx_bfly_load(const dsx_c32* buf, int b, int nb, dsx_c32* v) {
@@ -250,7 +386,7 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
   const int q = (s == 1) ? 0 : dsx_mod_s(b, s, inv_s);
   const int ps = b - q;
   const int dst = R * b - (R - 1) * q;
-  if constexpr (R >= 7) {
+  if constexpr (R == 7 || R == 11 || R == 13 || R == 17 || R == 19) {
     // odd prime: outputs are produced and scattered pair by pair (X[k], X[R-k]) so that only the
     // R inputs (folded in place into sums / differences) stay live in registers
     constexpr int HP = (R - 1) / 2;
@@ -292,6 +428,20 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
         buf[dst + s * k] = dsx_mul(dsx_mk(ar + bi, ai - br), tw[ps * k]);
         buf[dst + s * (R - k)] = dsx_mul(dsx_mk(ar - bi, ai + br), tw[ps * (R - k)]);
       }
+    }
+  } else if constexpr (dsx_comp<R>::R1 != 0) {
+    dsx_bfly_composite<R>(v);
+    buf[dst] = v[0];
+    if (unit_tw) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (int k = 1; k < R; ++k) buf[dst + s * k] = v[dsx_comp_pos<R>(k)];
+    } else {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (int k = 1; k < R; ++k) buf[dst + s * k] = dsx_mul(v[dsx_comp_pos<R>(k)], tw[ps * k]);
     }
   } else {
     dsx_bfly<R>::run(v);

@@ -838,6 +838,15 @@ __device__ __forceinline__ void fft_run(float2* buf, const float2* tw, const Row
       case 3: fft_pass<3, CPL>(buf, tw, M, s, inv_s, lane); break;
       case 4: fft_pass<4, CPL>(buf, tw, M, s, inv_s, lane); break;
       case 5: fft_pass<5, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 6: fft_pass<6, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 8: fft_pass<8, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 9: fft_pass<9, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 10: fft_pass<10, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 12: fft_pass<12, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 15: fft_pass<15, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 16: fft_pass<16, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 20: fft_pass<20, CPL>(buf, tw, M, s, inv_s, lane); break;
+      case 25: fft_pass<25, CPL>(buf, tw, M, s, inv_s, lane); break;
       case 7: fft_pass<7, CPL>(buf, tw, M, s, inv_s, lane); break;
       case 11: fft_pass<11, CPL>(buf, tw, M, s, inv_s, lane); break;
       case 13: fft_pass<13, CPL>(buf, tw, M, s, inv_s, lane); break;

@@ -60,12 +60,27 @@ inline int dwt_max_level(int n) {
   return l < 0 ? 0 : l;
 }
 
+// Radix list of a length: composite register butterflies first (fewer Stockham passes), then the
+// small primes, the odd-prime register butterflies (7..19) and, for anything else, generic passes.
 inline std::vector<int> factorize(int n) {
   std::vector<int> r;
-  while (n % 4 == 0) { r.push_back(4); n /= 4; }
-  while (n % 2 == 0) { r.push_back(2); n /= 2; }
-  while (n % 3 == 0) { r.push_back(3); n /= 3; }
-  while (n % 5 == 0) { r.push_back(5); n /= 5; }
+  int a = 0, b = 0, c = 0;  // powers of 2, 3, 5
+  while (n % 2 == 0) { ++a; n /= 2; }
+  while (n % 3 == 0) { ++b; n /= 3; }
+  while (n % 5 == 0) { ++c; n /= 5; }
+  while (a >= 4) { r.push_back(16); a -= 4; }
+  while (b >= 2) { r.push_back(9); b -= 2; }
+  while (c >= 2) { r.push_back(25); c -= 2; }
+  if (a == 3) { r.push_back(8); a = 0; }
+  if (a >= 1 && b >= 1) { r.push_back(6); --a; --b; }
+  if (a >= 2 && c >= 1) { r.push_back(20); a -= 2; --c; }
+  if (a >= 2 && b >= 1) { r.push_back(12); a -= 2; --b; }
+  if (a >= 1 && c >= 1) { r.push_back(10); --a; --c; }
+  if (b >= 1 && c >= 1) { r.push_back(15); --b; --c; }
+  while (a >= 2) { r.push_back(4); a -= 2; }
+  while (a >= 1) { r.push_back(2); --a; }
+  while (b >= 1) { r.push_back(3); --b; }
+  while (c >= 1) { r.push_back(5); --c; }
   for (int p = 7; n > 1; p += 2) {
     while (n % p == 0) { r.push_back(p); n /= p; }
   }
@@ -79,6 +94,15 @@ inline double pass_cost(int r) {
     case 3: return 13.3;
     case 4: return 12.0;
     case 5: return 16.0;
+    case 6: return 15.0;
+    case 8: return 15.0;
+    case 9: return 17.0;
+    case 10: return 19.0;
+    case 12: return 18.0;
+    case 15: return 22.0;
+    case 16: return 18.0;
+    case 20: return 22.0;
+    case 25: return 26.0;
     case 7: return 22.0;
     case 11: return 32.0;
     case 13: return 38.0;

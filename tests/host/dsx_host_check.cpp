@@ -24,7 +24,7 @@ static void run_passes(std::vector<dsx_c32>& buf, const std::vector<dsx_c32>& tw
     const int R = radix[pi];
     const float inv_s = 1.0f / (float)s;
     const int nb = M / R;
-    if (R == 2 || R == 3 || R == 4 || R == 5 || R == 7 || R == 11 || R == 13 || R == 17 || R == 19) {
+    if (R <= 20 || R == 25) {
       // read phase for every butterfly, then compute + scatter phase (what a wave does)
       std::vector<dsx_c32> regs((size_t)nb * R);
       for (int b = 0; b < nb; ++b) {
@@ -38,6 +38,15 @@ static void run_passes(std::vector<dsx_c32>& buf, const std::vector<dsx_c32>& tw
           case 13: dsx_bfly_load<13>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
           case 17: dsx_bfly_load<17>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
           case 19: dsx_bfly_load<19>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 6: dsx_bfly_load<6>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 8: dsx_bfly_load<8>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 9: dsx_bfly_load<9>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 10: dsx_bfly_load<10>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 12: dsx_bfly_load<12>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 15: dsx_bfly_load<15>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 16: dsx_bfly_load<16>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 20: dsx_bfly_load<20>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
+          case 25: dsx_bfly_load<25>(buf.data(), b, nb, &regs[(size_t)b * R]); break;
         }
       }
       for (int b = 0; b < nb; ++b) {
@@ -51,6 +60,15 @@ static void run_passes(std::vector<dsx_c32>& buf, const std::vector<dsx_c32>& tw
           case 13: dsx_bfly_store<13>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
           case 17: dsx_bfly_store<17>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
           case 19: dsx_bfly_store<19>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R]); break;
+          case 6: dsx_bfly_store<6>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R], s * R == M); break;
+          case 8: dsx_bfly_store<8>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R], s * R == M); break;
+          case 9: dsx_bfly_store<9>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R], s * R == M); break;
+          case 10: dsx_bfly_store<10>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R], s * R == M); break;
+          case 12: dsx_bfly_store<12>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R], s * R == M); break;
+          case 15: dsx_bfly_store<15>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R], s * R == M); break;
+          case 16: dsx_bfly_store<16>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R], s * R == M); break;
+          case 20: dsx_bfly_store<20>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R], s * R == M); break;
+          case 25: dsx_bfly_store<25>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R], s * R == M); break;
         }
       }
     } else {
