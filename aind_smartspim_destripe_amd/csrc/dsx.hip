@@ -73,7 +73,28 @@ struct dsx_ctx {
   std::vector<ProfRec> prof;
   size_t workspace_bytes = 0;
   int ablate = 0;  // DSX_ABLATE environment variable: row-filter phase ablation, diagnosis only
+  // sub-cohort streams: a cohort is split into parts that run their launch chains concurrently, so that
+  // latency-bound (march) and compute-bound (row filter) kernels of different parts overlap on the chip
+  static constexpr int kMaxStreams = 8;
+  int n_streams = 4;
+  hipStream_t aux[kMaxStreams] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {};
 };
+
+namespace {
+// Buffers of one part of a cohort (planes [po, po + nb) of the workspace) and the stream it runs on.
+struct CohortView {
+  hipStream_t stream;
+  float* ws;
+  dsx::PlaneStats* stats;
+  unsigned* minmax;
+  unsigned* hist;
+  float* thr;
+  float* otsu;
+  int* cfg;
+  double* means;
+};
+}  // namespace
 
 namespace {
 
@@ -181,12 +202,15 @@ void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg)
 }
 
 // One cohort of nb planes through the whole chain (asynchronous).
-int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out, int out_dtype,
-               int32_t* d_cfg_used) {
+int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype, int nb, void* d_out,
+               int out_dtype, int32_t* d_cfg_used) {
   const dsx::Plan& p = ctx->plan;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = v.stream;
   const int L = p.L;
-  DSX_HIP(hipMemsetAsync(ctx->d_ctl, 0, ctx->ctl_zero_bytes, s));
+  const int Lc = L > 0 ? L : 1;
+  DSX_HIP(hipMemsetAsync(v.stats, 0, sizeof(dsx::PlaneStats) * nb, s));
+  DSX_HIP(hipMemsetAsync(v.minmax, 0, sizeof(unsigned) * 2 * Lc * nb, s));
+  DSX_HIP(hipMemsetAsync(v.hist, 0, sizeof(unsigned) * 256 * Lc * nb, s));
 
   // ---- forward transform ------------------------------------------------------------------
   for (int l = 0; l < L; ++l) {
@@ -195,15 +219,15 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
     memset(&f, 0, sizeof(f));
     f.in = d_in;
     f.in_plane_stride = (long long)p.H * p.W;
-    f.ws = ctx->d_ws;
+    f.ws = v.ws;
     f.ws_plane_stride = p.plane_floats;
     f.in_off = (l > 0) ? p.lv[l - 1].aa_off : 0;
     f.H = lp.hin; f.W = lp.win; f.ldin = lp.ldin;
     f.aa_off = lp.aa_off; f.da_off = lp.da_off;
     f.h = lp.h; f.w = lp.w; f.ld = lp.ld;
-    f.minmax = ctx->d_minmax;
+    f.minmax = v.minmax;
     f.lvl = l; f.L = L;
-    f.stats = ctx->d_stats;
+    f.stats = v.stats;
     f.fg_cutoff = ctx->fg_cutoff;
     f.nstrips = (lp.w + dsx::kMarchOut - 1) / dsx::kMarchOut;
     march_segments(nb, f.nstrips, lp.h, &f.nseg, &f.rows_per_seg);
@@ -226,12 +250,12 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
   for (int l = 0; l < L; ++l) {
     const dsx::LevelPlan& lp = p.lv[l];
     dsx::HistArgs a;
-    a.ws = ctx->d_ws;
+    a.ws = v.ws;
     a.ws_plane_stride = p.plane_floats;
     a.da_off = lp.da_off;
     a.h = lp.h; a.w = lp.w; a.ld = lp.ld;
-    a.minmax = ctx->d_minmax;
-    a.hist = ctx->d_hist;
+    a.minmax = v.minmax;
+    a.hist = v.hist;
     a.lvl = l; a.L = L;
     a.rows_per_block = 32;
     dim3 grid((lp.h + a.rows_per_block - 1) / a.rows_per_block, nb);
@@ -241,15 +265,15 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
   }
   if (L > 0) {
     dsx::OtsuArgs a;
-    a.stats = ctx->d_stats;
+    a.stats = v.stats;
     a.npix = (double)p.H * (double)p.W;
     a.high_int = ctx->high_int;
-    a.minmax = ctx->d_minmax;
-    a.hist = ctx->d_hist;
-    a.thr = ctx->d_thr;
-    a.otsu = ctx->d_otsu;
-    a.cfg = ctx->d_cfg;
-    a.means = ctx->d_means;
+    a.minmax = v.minmax;
+    a.hist = v.hist;
+    a.thr = v.thr;
+    a.otsu = v.otsu;
+    a.cfg = v.cfg;
+    a.means = v.means;
     a.max_thr[0] = (float)ctx->cfg[0].max_threshold;
     a.max_thr[1] = (float)ctx->cfg[1].max_threshold;
     a.L = L;
@@ -257,7 +281,7 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
     hipLaunchKernelGGL(dsx::k_otsu, dim3(L, nb), dim3(64), 0, s, a);
     DSX_HIP(hipGetLastError());
     if (d_cfg_used)
-      DSX_HIP(hipMemcpyAsync(d_cfg_used, ctx->d_cfg, sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, s));
+      DSX_HIP(hipMemcpyAsync(d_cfg_used, v.cfg, sizeof(int32_t) * nb, hipMemcpyDeviceToDevice, s));
   } else if (d_cfg_used) {
     DSX_HIP(hipMemsetAsync(d_cfg_used, 0, sizeof(int32_t) * nb, s));
   }
@@ -268,12 +292,12 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
     const dsx::LevelPlan& lp = p.lv[l];
     dsx::RowArgs a;
     memset(&a, 0, sizeof(a));
-    a.ws = ctx->d_ws;
+    a.ws = v.ws;
     a.ws_plane_stride = p.plane_floats;
     a.da_off = lp.da_off;
     a.h = lp.h; a.w = lp.w; a.ld = lp.ld;
-    a.thr = ctx->d_thr;
-    a.cfg = ctx->d_cfg;
+    a.thr = v.thr;
+    a.cfg = v.cfg;
     a.lvl = l; a.L = L;
     a.lvl_active[0] = p.cfg_levels[0];
     a.lvl_active[1] = p.cfg_levels[1];
@@ -295,7 +319,7 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
   for (int l = L - 1; l >= (L > 0 ? 0 : -1); --l) {
     dsx::FinalArgs f;
     memset(&f, 0, sizeof(f));
-    f.ws = ctx->d_ws;
+    f.ws = v.ws;
     f.ws_plane_stride = p.plane_floats;
     if (l >= 0) {
       const dsx::LevelPlan& lp = p.lv[l];
@@ -308,7 +332,7 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
     const bool last = (l <= 0);
     if (!last) {
       const dsx::LevelPlan& lo = p.lv[l - 1];
-      f.ws_out = ctx->d_ws;
+      f.ws_out = v.ws;
       f.out_off = lo.aa_off;
       f.hout = lo.h; f.wout = lo.w; f.ldout = lo.ld;
     } else {
@@ -341,6 +365,46 @@ int run_cohort(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out
 
 size_t elem_size(int dtype) { return dtype == DSX_U16 ? 2 : 4; }
 
+CohortView make_view(dsx_ctx* ctx, int po, hipStream_t stream) {
+  const int Lc = ctx->plan.L > 0 ? ctx->plan.L : 1;
+  CohortView v;
+  v.stream = stream;
+  v.ws = ctx->d_ws + (size_t)po * ctx->plan.plane_floats;
+  v.stats = ctx->d_stats + po;
+  v.minmax = ctx->d_minmax + (size_t)po * Lc * 2;
+  v.hist = ctx->d_hist + (size_t)po * Lc * 256;
+  v.thr = ctx->d_thr + (size_t)po * Lc;
+  v.otsu = ctx->d_otsu + (size_t)po * Lc;
+  v.cfg = ctx->d_cfg + po;
+  v.means = ctx->d_means + 2 * (size_t)po;
+  return v;
+}
+
+// One cohort (<= max_batch planes), split into parts on the context's streams.
+int run_cohort_split(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out, int out_dtype,
+                     int32_t* d_cfg_used, size_t in_plane, size_t out_plane) {
+  int parts = ctx->n_streams;
+  if (ctx->profiling || ctx->stop_after != 0) parts = 1;
+  while (parts > 1 && nb / parts < 16) --parts;  // keep every part big enough to fill the chip
+  if (parts <= 1) return run_cohort(ctx, make_view(ctx, 0, ctx->stream), d_in, in_dtype, nb, d_out, out_dtype, d_cfg_used);
+  DSX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+  const int per = (nb + parts - 1) / parts;
+  for (int i = 0; i < parts; ++i) {
+    const int po = i * per, n = std::min(per, nb - po);
+    if (n <= 0) break;
+    hipStream_t st = (i == 0) ? ctx->stream : ctx->aux[i];
+    if (i > 0) DSX_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
+    const int rc = run_cohort(ctx, make_view(ctx, po, st), (const char*)d_in + po * in_plane, in_dtype, n,
+                              (char*)d_out + po * out_plane, out_dtype, d_cfg_used ? d_cfg_used + po : nullptr);
+    if (rc != DSX_OK) return rc;
+    if (i > 0) {
+      DSX_HIP(hipEventRecord(ctx->ev_join[i], st));
+      DSX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
+    }
+  }
+  return DSX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -368,7 +432,13 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
   dsx_ctx* c = new dsx_ctx();
   c->device = device;
   if (const char* ab = getenv("DSX_ABLATE")) c->ablate = atoi(ab);
+  if (const char* ns = getenv("DSX_STREAMS")) c->n_streams = std::max(1, std::min(atoi(ns), (int)dsx_ctx::kMaxStreams));
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  for (int i = 1; i < dsx_ctx::kMaxStreams && e == hipSuccess; ++i) {
+    e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&c->t0);
   if (e == hipSuccess) e = hipEventCreate(&c->t1);
   if (e != hipSuccess) {
@@ -388,6 +458,11 @@ void dsx_destroy(dsx_ctx* ctx) {
   free_plan_buffers(ctx);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  for (int i = 1; i < dsx_ctx::kMaxStreams; ++i) {
+    if (ctx->aux[i]) { (void)hipStreamSynchronize(ctx->aux[i]); (void)hipStreamDestroy(ctx->aux[i]); }
+    if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+  }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -522,9 +597,9 @@ int dsx_run_device(dsx_ctx* ctx, const void* d_in, int in_dtype, int n, void* d_
   const size_t out_plane = (size_t)p.Hout * p.Wout * elem_size(out_dtype);
   for (int start = 0; start < n; start += ctx->max_batch) {
     const int nb = std::min(ctx->max_batch, n - start);
-    const int rc = run_cohort(ctx, (const char*)d_in + start * in_plane, in_dtype, nb,
-                              (char*)d_out + start * out_plane, out_dtype,
-                              d_cfg_used ? d_cfg_used + start : nullptr);
+    const int rc = run_cohort_split(ctx, (const char*)d_in + start * in_plane, in_dtype, nb,
+                                    (char*)d_out + start * out_plane, out_dtype,
+                                    d_cfg_used ? d_cfg_used + start : nullptr, in_plane, out_plane);
     if (rc != DSX_OK) return rc;
     ctx->last_n = nb;
   }
@@ -568,7 +643,8 @@ int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, i
     const int nb = std::min(B, n - start);
     DSX_HIP(hipMemcpyAsync(ctx->d_stage_in, (const char*)in + start * in_plane, in_plane * nb,
                            hipMemcpyHostToDevice, ctx->stream));
-    const int rc = run_cohort(ctx, ctx->d_stage_in, in_dtype, nb, ctx->d_stage_out, out_dtype, d_cfg);
+    const int rc = run_cohort_split(ctx, ctx->d_stage_in, in_dtype, nb, ctx->d_stage_out, out_dtype, d_cfg,
+                                    in_plane, out_plane);
     if (rc != DSX_OK) return rc;
     ctx->last_n = nb;
     if (ctx->stop_after == 0)
