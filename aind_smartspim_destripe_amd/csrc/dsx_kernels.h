@@ -625,33 +625,50 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
   __syncthreads();
   const float denom = qmax - qmin;
   const float step = denom / 256.0f;
-  unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  const float scale = 256.0f / denom;
+  // Bin of q = largest i with edges[i] <= q, edges[i] = i * step + qmin (numpy's estimate-then-correct
+  // rule ends there too).  The estimate (q - qmin) * scale is within 1e-4 of the exact position, so
+  // only values within 1e-3 of an integer need the comparison against the actual edges.
+  auto bin_of = [&](float q) {
+    const float fi = (q - qmin) * scale;
+    int idx = min((int)fi, 255);
+    const float fr = fi - (float)idx;
+    if (fr < 1e-3f || fr > 0.999f) {
+      const float e_lo = __fadd_rn(__fmul_rn((float)idx, step), qmin);
+      const float e_hi = (idx == 255) ? qmax : __fadd_rn(__fmul_rn((float)(idx + 1), step), qmin);
+      if (q < e_lo) idx -= 1;
+      else if (idx != 255 && q >= e_hi) idx += 1;
+      idx = max(idx, 0);
+    }
+    return idx;
+  };
+  // the four lowest bins hold most of the mass: byte-packed per-lane counters, flushed before overflow
+  unsigned packed = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, since_flush = 0;
+  auto count = [&](int idx) {
+    if (idx < 4) packed += 1u << (8 * idx);
+    else atomicAdd(&s_h[idx], 1u);
+  };
+  auto flush = [&]() {
+    c0 += packed & 0xFFu; c1 += (packed >> 8) & 0xFFu; c2 += (packed >> 16) & 0xFFu; c3 += packed >> 24;
+    packed = 0;
+    since_flush = 0;
+  };
   const float* da = a.ws + plane * a.ws_plane_stride + a.da_off;
   const int r0 = blockIdx.x * a.rows_per_block;
   const int r1 = min(a.h, r0 + a.rows_per_block);
   for (int r = r0 + wave; r < r1; r += 4) {
-    const float* row = da + (long long)r * a.ld;
-    for (int c = lane; c < a.w; c += 64) {
-      const float v = row[c];
-      const float q = v * v;
-      int idx = (int)(((q - qmin) / denom) * 256.0f);
-      idx = min(idx, 255);
-      // numpy's +-1 correction against the actual edges  edges[i] = i * step + min, edges[256] = max
-      const float e_lo = __fadd_rn(__fmul_rn((float)idx, step), qmin);
-      const float e_hi = (idx == 255) ? qmax : __fadd_rn(__fmul_rn((float)(idx + 1), step), qmin);
-      if (q < e_lo) {
-        idx -= 1;
-      } else if (idx != 255 && q >= e_hi) {
-        idx += 1;
-      }
-      idx = max(idx, 0);
-      c0 += (idx == 0);
-      c1 += (idx == 1);
-      c2 += (idx == 2);
-      c3 += (idx == 3);
-      if (idx >= 4) atomicAdd(&s_h[idx], 1u);
+    const float* row = da + (long long)r * a.ld;  // 16-byte aligned, pitch a multiple of 4
+    for (int c = 4 * lane; c < a.w; c += 4 * 64) {
+      const float4 v = *(const float4*)(row + c);
+      count(bin_of(v.x * v.x));
+      if (c + 1 < a.w) count(bin_of(v.y * v.y));
+      if (c + 2 < a.w) count(bin_of(v.z * v.z));
+      if (c + 3 < a.w) count(bin_of(v.w * v.w));
+      since_flush += 4;
+      if (since_flush >= 252) flush();
     }
   }
+  flush();
   c0 = __reduce_add_sync(~0ull, c0);
   c1 = __reduce_add_sync(~0ull, c1);
   c2 = __reduce_add_sync(~0ull, c2);
