@@ -1001,16 +1001,77 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   const unsigned k1 = (unsigned)(N - 1) >> 1;
   const unsigned rhi = bisect_pk16<E>(hs, k1, k1);
   unsigned below = __reduce_add_sync(~0ull, count_below_pk16<E>(hs, rhi ^ 0x80008000u));
+  // Low halves of the candidates (elements whose high half equals the selected one), in unsigned
+  // order; all other elements get the maximum 0xFFFF.
   unsigned lsel[E];
   {
     const dsx_s16x2 rv = as_s16x2(rhi ^ 0x80008000u);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const dsx_s16x2 eq = (as_s16x2(hs[e]) == rv);       // -1 where the high half matches
-      lsel[e] = (ls[e] & as_u32(eq)) | (0x7FFF7FFFu & ~as_u32(eq));  // others: +max (never below)
+      const dsx_s16x2 eq = (as_s16x2(hs[e]) == rv);  // -1 where the high half matches
+      lsel[e] = ((ls[e] ^ 0x80008000u) & as_u32(eq)) | ~as_u32(eq);
     }
   }
-  const unsigned rlo = bisect_pk16<E>(lsel, k1 - (below & 0xFFFFu), k1 - (below >> 16));
+  // Rank inside the bucket.  The bucket is usually tiny (a 2^-7 relative slice of the value range),
+  // so walk its distinct values in ascending order: next value = lower bound + wave-min of the
+  // wrapped differences; stop when the multiplicities passed exceed the rank.  Bounded number of
+  // rounds; anything left falls back to the 16-step bisection of the low half.
+  // (The loop state is wave-uniform, but mixing SGPR- and VGPR-resident values across the loop
+  // crashes ROCm 7.2's "SI Fix SGPR copies"; a VGPR zero makes all of it vector state.)
+  unsigned vz;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+  unsigned rank_a = (k1 - (below & 0xFFFFu)) | vz, rank_b = (k1 - (below >> 16)) | vz;
+  unsigned lb = vz, rlo = vz;
+  unsigned done_a = vz, done_b = vz;
+  for (int round = 0; round < ((a.ablate & 8) ? 0 : 12) && !(done_a & done_b); ++round) {
+    typedef unsigned short dsx_u16x2 __attribute__((ext_vector_type(2)));
+    union U { unsigned u; dsx_u16x2 v; };
+    U lbv; lbv.u = lb;
+    U mn; mn.u = 0xFFFFFFFFu;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      U x; x.u = lsel[e];
+      U d; d.v = x.v - lbv.v;  // elements below the bound wrap around to large values
+      mn.v = __builtin_elementwise_min(mn.v, d.v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      U t; t.u = (unsigned)__shfl_xor((int)mn.u, o);
+      mn.v = __builtin_elementwise_min(mn.v, t.v);
+    }
+    U val; val.v = lbv.v + mn.v;  // smallest remaining value per row
+    // multiplicity of that value: count zero differences
+    U cnt; cnt.u = 0;
+    const dsx_u16x2 one = {1, 1};
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      U x; x.u = lsel[e];
+      U z; z.v = x.v - val.v;
+      cnt.v += one - __builtin_elementwise_min(z.v, one);
+    }
+    const unsigned c = __reduce_add_sync(~0ull, cnt.u);
+    const unsigned va = val.u & 0xFFFFu, vb = val.u >> 16;
+    if (!done_a) {
+      if (rank_a < (c & 0xFFFFu) || va == 0xFFFFu) { rlo = (rlo & 0xFFFF0000u) | va; done_a = 1u; }
+      else { rank_a -= (c & 0xFFFFu); lb = (lb & 0xFFFF0000u) | (va + 1u); }
+    }
+    if (!done_b) {
+      if (rank_b < (c >> 16) || vb == 0xFFFFu) { rlo = (rlo & 0xFFFFu) | (vb << 16); done_b = 1u; }
+      else { rank_b -= (c >> 16); lb = (lb & 0xFFFFu) | ((vb + 1u) << 16); }
+    }
+  }
+  // the state is uniform: read it back into scalars for the (wave-uniform) fallback decision
+  const bool all_done = (__builtin_amdgcn_readfirstlane(done_a & done_b) != 0);
+  rlo = __builtin_amdgcn_readfirstlane(rlo);
+  if (!all_done) {
+    // dense bucket: bisection of the low half (signed-order operands, sentinel never counted)
+    unsigned lsg[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) lsg[e] = lsel[e] ^ 0x80008000u;
+    const unsigned r2 = bisect_pk16<E>(lsg, k1 - (below & 0xFFFFu), k1 - (below >> 16));
+    if (!__builtin_amdgcn_readfirstlane(done_a)) rlo = (rlo & 0xFFFF0000u) | (r2 & 0xFFFFu);
+    if (!__builtin_amdgcn_readfirstlane(done_b)) rlo = (rlo & 0xFFFFu) | (r2 & 0xFFFF0000u);
+  }
   const unsigned keya = ((rhi & 0xFFFFu) << 16) | (rlo & 0xFFFFu);
   const unsigned keyb = (rhi & 0xFFFF0000u) | (rlo >> 16);
   meda = key_f32(keya);
