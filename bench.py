@@ -43,8 +43,8 @@ def init_dist(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
-        return None, 0, 1, 0
+    if world == 1 and "RANK" not in os.environ:
+        return None, 0, 1, 0  # plain `python bench.py`: no process group needed
     import torch
     import torch.distributed as dist
 
@@ -102,6 +102,11 @@ def cpu_baseline(n_planes):
 
 
 def main():
+    # Only the JSON line may reach stdout: library banners (Gloo, RCCL) are written to fd 1 directly,
+    # so fd 1 is pointed at stderr for the duration of the run and the line goes to the saved fd.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -201,6 +206,7 @@ def main():
                             "uint16 out, inputs resident in HBM".format(args.batch),
                 "slices_per_gpu": args.batch,
                 "cohort": min(args.cohort, args.batch),
+                "sub_cohort_streams": int(os.environ.get("DSX_STREAMS", "4")),
                 "levels": info.levels,
                 "fft_len": [info.fft_len[i] for i in range(info.levels)],
                 "planes_with_cells_config": n_cells,
@@ -225,7 +231,7 @@ def main():
             result["kernel_ms"] = breakdown
         if world == 1 and args.cpu_planes > 0:
             result["cpu_baseline"] = cpu_baseline(args.cpu_planes)
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
 
     d_in.free()
     d_out.free()
