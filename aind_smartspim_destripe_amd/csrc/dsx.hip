@@ -208,9 +208,25 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   hipStream_t s = v.stream;
   const int L = p.L;
   const int Lc = L > 0 ? L : 1;
-  DSX_HIP(hipMemsetAsync(v.stats, 0, sizeof(dsx::PlaneStats) * nb, s));
-  DSX_HIP(hipMemsetAsync(v.minmax, 0, sizeof(unsigned) * 2 * Lc * nb, s));
-  DSX_HIP(hipMemsetAsync(v.hist, 0, sizeof(unsigned) * 256 * Lc * nb, s));
+  {
+    // stats: 32 B per plane; minmax: 8 Lc B per plane (parts start at even planes -> 16-byte aligned
+    // except for odd Lc * po, handled by rounding the count up inside the part's own slice);
+    // hist: 1 KiB per plane and level
+    const int n0 = (int)(sizeof(dsx::PlaneStats) * nb / 16);
+    const int n2 = (int)(sizeof(unsigned) * 256 * Lc * (size_t)nb / 16);
+    const size_t mm_bytes = sizeof(unsigned) * 2 * Lc * (size_t)nb;
+    if ((mm_bytes % 16) == 0 && (((uintptr_t)v.minmax) % 16) == 0) {
+      const int n1 = (int)(mm_bytes / 16);
+      const int total = n0 + n1 + n2;
+      hipLaunchKernelGGL(dsx::k_zero3, dim3(std::min((total + 255) / 256, 1024)), dim3(256), 0, s, (uint4*)v.stats, n0,
+                         (uint4*)v.minmax, n1, (uint4*)v.hist, n2);
+      DSX_HIP(hipGetLastError());
+    } else {
+      DSX_HIP(hipMemsetAsync(v.stats, 0, sizeof(dsx::PlaneStats) * nb, s));
+      DSX_HIP(hipMemsetAsync(v.minmax, 0, mm_bytes, s));
+      DSX_HIP(hipMemsetAsync(v.hist, 0, sizeof(unsigned) * 256 * Lc * nb, s));
+    }
+  }
 
   // ---- forward transform ------------------------------------------------------------------
   for (int l = 0; l < L; ++l) {

@@ -83,6 +83,17 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One launch instead of three hipMemsetAsync calls (each ~27 us of fill-kernel + launch latency) to zero
+// the control block of a cohort part: plane statistics, min/max words, histograms (16-byte units).
+__global__ __launch_bounds__(256) void k_zero3(uint4* p0, int n0, uint4* p1, int n1, uint4* p2, int n2) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n0 + n1 + n2; i += gridDim.x * 256) {
+    if (i < n0) p0[i] = z;
+    else if (i < n0 + n1) p1[i - n0] = z;
+    else p2[i - n0 - n1] = z;
+  }
+}
+
 // ================================================================================================
 // K1: forward level
 // ================================================================================================

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libdsx_hip.so")
+# DSX_LIB overrides the library path (A/B runs of two builds inside one GPU session)
+LIB_PATH = os.environ.get("DSX_LIB") or os.path.join(_HERE, "_lib", "libdsx_hip.so")
 
 DSX_U16, DSX_F32 = 0, 1
 DSX_WAVELET_DB3 = 3

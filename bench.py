@@ -187,6 +187,13 @@ def main():
         ms_per_step = 1e3 * wall / args.steps
         dev_ms_per_step = dev_ms / args.steps
         achieved = args.batch * ALGO_BYTES_PER_SLICE / (dev_ms_per_step * 1e-3) / 1e9
+        # HBM bytes per launch chain from the PMC counters (collected with rocprofv3 in separate
+        # passes and corrected as MI355X_MICROARCH.md prescribes; see profiles/r1_traffic.json)
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r1_traffic.json")
+        if os.path.exists(tpath) and args.batch == 256:
+            with open(tpath) as f:
+                traffic = int(json.load(f)["hbm_bytes_per_step"])
         result = {
             "metric": "2048x2048 uint16 slices/s destriped",
             "value": round(value, 2),
@@ -220,7 +227,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": args.batch * ALGO_BYTES_PER_SLICE,
                 "device_ms_per_launch": round(dev_ms_per_step, 4),
                 "read_only_frac": round(achieved / 2 / HBM_PEAK_GBS, 5),
