@@ -1,8 +1,9 @@
 // dsx.hip -- C ABI of the MI355X destripe engine (see include/dsx.h) and the launch pipeline.
 //
-// Pipeline per cohort of <= max_batch planes (one HIP stream, no host synchronisation inside):
-//   memset(control)  ->  k_dwt_fwd x L  ->  k_hist x L  ->  k_otsu  ->  k_rowfilter x L
-//   ->  k_idwt x (L-1)  ->  k_idwt<final>
+// Pipeline per cohort part (a cohort of <= max_batch planes is split into parts that run on separate
+// HIP streams; no host synchronisation inside):
+//   k_zero3  ->  k_fwd_march x L  ->  k_hist x L  ->  k_otsu  ->  k_rowfilter x L
+//   ->  k_inv_march<pyramid> x (L-1)  ->  k_inv_march<final>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>

@@ -1,12 +1,12 @@
 // dsx_kernels.h -- hand-written gfx950 kernels of the destripe path.
 //
-//   k_dwt_fwd    log(1+x) + one 2-D db3 analysis level, only the aa / da (= cH) subbands;
+//   k_fwd_march  log(1+x) + one 2-D db3 analysis level, only the aa / da (= cH) subbands;
 //                fused: fg/bg statistic (level 1) and min/max of cH^2          
 //   k_hist       256-bin numpy-rule histogram of cH^2 per plane and level       (K2b)
 //   k_otsu       config decision + Otsu arg-max + threshold                      (K3)
 //   k_rowfilter  mask, exact row median, in-paint, FFT low-pass with the packed-index gain
 //                quirk, Delta = -(1 - mask) LP(inpainted); two rows per complex FFT (K4)
-//   k_idwt       one synthesis level of the Delta pyramid; the last level fuses
+//   k_inv_march  one synthesis level of the Delta pyramid; the last level fuses
 //                (1 + x) exp(c0) + 1, flat/dark correction and the output cast    (K5, K6)
 //
 // Reference semantics: /root/reference/code/aind_smartspim_destripe/filtering.py:139-224
@@ -95,183 +95,7 @@ __global__ __launch_bounds__(256) void k_zero3(uint4* p0, int n0, uint4* p1, int
 }
 
 // ================================================================================================
-// K1: forward level
-// ================================================================================================
-struct FwdArgs {
-  const void* in;            // IN_KIND 0/1: pixels [B][hin][win]; IN_KIND 2: unused
-  long long in_plane_stride; // elements
-  float* ws;                 // workspace base
-  long long ws_plane_stride; // floats per plane
-  long long in_off;          // IN_KIND 2: offset of aa_{l-1} inside a plane's workspace
-  int hin, win, ldin;
-  long long aa_off, da_off;
-  int h, w, ld;
-  unsigned* minmax;          // [B][L][2]: {~bits(min q), bits(max q)}, zero-initialised
-  int lvl, L;
-  PlaneStats* stats;         // level 1 only
-  float fg_cutoff;           // pixel is foreground iff (float)pixel >= fg_cutoff
-};
-
-constexpr int kFwdTH = 16, kFwdTW = 64;
-constexpr int kFwdIR = 2 * kFwdTH + 4, kFwdIC = 2 * kFwdTW + 4;  // 36 x 132 input tile
-
-template <int IN_KIND>
-__device__ __forceinline__ float fwd_load1(const FwdArgs& a, const void* base, long long off) {
-  if (IN_KIND == 0) return (float)((const uint16_t*)base)[off];
-  return ((const float*)base)[off];
-}
-
-// IN_KIND: 0 = uint16 pixels (log fused), 1 = float32 pixels (log fused), 2 = float32 aa_{l-1}
-template <int IN_KIND>
-__global__ __launch_bounds__(256) void k_dwt_fwd(FwdArgs a) {
-  constexpr int TH = kFwdTH, TW = kFwdTW, IR = kFwdIR, IC = kFwdIC;
-  __shared__ __attribute__((aligned(16))) float s_in[IR][IC];
-  __shared__ float s_v[2][TH][2][TW + 4];  // [lo|hi][row][column parity][column / 2]
-  constexpr float LO[6] = DSX_DEC_LO;
-  constexpr float HI[6] = DSX_DEC_HI;
-
-  const int tid = threadIdx.x;
-  const int plane = blockIdx.z;
-  const int i0 = blockIdx.y * TH, j0 = blockIdx.x * TW;
-  const int r_base = 2 * i0 - 4, c_base = 2 * j0 - 4;
-
-  const void* src;
-  if (IN_KIND == 2) {
-    src = a.ws + plane * a.ws_plane_stride + a.in_off;
-  } else if (IN_KIND == 0) {
-    src = (const uint16_t*)a.in + plane * a.in_plane_stride;
-  } else {
-    src = (const float*)a.in + plane * a.in_plane_stride;
-  }
-
-  double st_fg = 0.0, st_all = 0.0;
-  unsigned st_cnt = 0;
-
-  const bool vec_ok = (c_base >= 0) && (c_base + IC <= a.win) && ((a.ldin & 3) == 0);
-  if (vec_ok) {
-    constexpr int NV = IC / 4;  // 33 groups of 4 pixels
-    for (int idx = tid; idx < IR * NV; idx += 256) {
-      const int lr = idx / NV, v = idx - lr * NV;
-      const int gr_raw = r_base + lr;
-      const int gr = reflect_idx(gr_raw, a.hin);
-      const long long off = (long long)gr * a.ldin + c_base + 4 * v;
-      float f[4];
-      if (IN_KIND == 0) {
-        const uint2 raw = *(const uint2*)((const uint16_t*)src + off);
-        f[0] = (float)(raw.x & 0xFFFFu);
-        f[1] = (float)(raw.x >> 16);
-        f[2] = (float)(raw.y & 0xFFFFu);
-        f[3] = (float)(raw.y >> 16);
-      } else {
-        const float4 raw = *(const float4*)((const float*)src + off);
-        f[0] = raw.x; f[1] = raw.y; f[2] = raw.z; f[3] = raw.w;
-      }
-      if (IN_KIND != 2) {
-        const bool own_row = (lr >= 4) && (lr < 4 + 2 * TH) && (gr_raw < a.hin);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int lc = 4 * v + e;
-          if (own_row && lc >= 4 && lc < 4 + 2 * TW) {  // vec_ok: every column is inside the plane
-            st_all += (double)f[e];
-            if (f[e] >= a.fg_cutoff) { st_fg += (double)f[e]; st_cnt++; }
-          }
-          f[e] = __logf(1.0f + f[e]);
-        }
-      }
-      *(float4*)&s_in[lr][4 * v] = make_float4(f[0], f[1], f[2], f[3]);
-    }
-  } else {
-    for (int idx = tid; idx < IR * IC; idx += 256) {
-      const int lr = idx / IC, lc = idx - lr * IC;
-      const int gr_raw = r_base + lr, gc_raw = c_base + lc;
-      const int gr = reflect_idx(gr_raw, a.hin);
-      const int gc = reflect_idx(gc_raw, a.win);
-      float f = fwd_load1<IN_KIND>(a, src, (long long)gr * a.ldin + gc);
-      if (IN_KIND != 2) {
-        const bool own = (lr >= 4) && (lr < 4 + 2 * TH) && (lc >= 4) && (lc < 4 + 2 * TW) &&
-                         (gr_raw < a.hin) && (gc_raw < a.win);
-        if (own) {
-          st_all += (double)f;
-          if (f >= a.fg_cutoff) { st_fg += (double)f; st_cnt++; }
-        }
-        f = __logf(1.0f + f);
-      }
-      s_in[lr][lc] = f;
-    }
-  }
-  __syncthreads();
-
-  // axis 0 (rows): a0 = lo, d0 = hi;  out[ii] = sum_k f[k] * in[2 ii + 5 - k]
-  for (int idx = tid; idx < TH * IC; idx += 256) {
-    const int ii = idx / IC, lc = idx - ii * IC;
-    float lo = 0.f, hi = 0.f;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const float x = s_in[2 * ii + 5 - k][lc];
-      lo = fmaf(LO[k], x, lo);
-      hi = fmaf(HI[k], x, hi);
-    }
-    s_v[0][ii][lc & 1][lc >> 1] = lo;
-    s_v[1][ii][lc & 1][lc >> 1] = hi;
-  }
-  __syncthreads();
-
-  // axis 1 (columns), low-pass only: aa = lo(a0), da = lo(d0)
-  float qmin = __builtin_huge_valf(), qmax = 0.f;
-  float* aa = a.ws + plane * a.ws_plane_stride + a.aa_off;
-  float* da = a.ws + plane * a.ws_plane_stride + a.da_off;
-  for (int idx = tid; idx < TH * TW; idx += 256) {
-    const int ii = idx / TW, jj = idx - ii * TW;
-    const int i = i0 + ii, j = j0 + jj;
-    float out[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const float* e = s_v[b][ii][0];
-      const float* o = s_v[b][ii][1];
-      float acc = LO[0] * o[jj + 2];
-      acc = fmaf(LO[1], e[jj + 2], acc);
-      acc = fmaf(LO[2], o[jj + 1], acc);
-      acc = fmaf(LO[3], e[jj + 1], acc);
-      acc = fmaf(LO[4], o[jj], acc);
-      acc = fmaf(LO[5], e[jj], acc);
-      out[b] = acc;
-    }
-    if (i < a.h && j < a.w) {
-      aa[(long long)i * a.ld + j] = out[0];
-      da[(long long)i * a.ld + j] = out[1];
-      const float q = out[1] * out[1];
-      qmin = fminf(qmin, q);
-      qmax = fmaxf(qmax, q);
-    }
-  }
-  qmin = wave_min_f32(qmin);
-  qmax = wave_max_f32(qmax);
-  if ((tid & 63) == 0) {
-    unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
-    if (qmin <= qmax) {  // at least one valid output in this wave
-      atomicMax(&mm[0], ~as_u32(qmin));
-      atomicMax(&mm[1], as_u32(qmax));
-    }
-  }
-  if (IN_KIND != 2) {
-    st_fg = wave_sum_f64(st_fg);
-    st_all = wave_sum_f64(st_all);
-    unsigned long long c = st_cnt;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((tid & 63) == 0) {
-      PlaneStats* st = a.stats + plane;
-      if (st_all != 0.0) atomicAdd(&st->sum_all, st_all);
-      if (c != 0) {
-        atomicAdd(&st->sum_fg, st_fg);
-        atomicAdd(&st->cnt_fg, c);
-      }
-    }
-  }
-}
-
-// ================================================================================================
-// K1m: level-1 forward transform, "marching" form (the HBM-heavy level: u16/f32 plane in, aa/da out)
+// K1: forward transform level, "marching" form
 //
 // One WAVE owns a strip of 256 input columns (4 per lane, one 8/16-byte load per lane and row) and
 // streams down the rows with a 6-row sliding window in registers, so the column (axis-0) filter
@@ -1186,120 +1010,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
 }
 
 // ================================================================================================
-// K5 / K6: synthesis level of the Delta pyramid; FINAL fuses (1 + x) exp(c0) + 1, shading, cast
-// ================================================================================================
-struct InvArgs {
-  float* ws;
-  long long ws_plane_stride;
-  long long c_off, d_off;  // c_l (approximation buffer of level l) and Delta_l
-  int hc, wc, ldc;
-  int has_c;               // 0 at the coarsest level (c_L == 0)
-  int has_pyr;             // 0 when no level runs at all (level == 0: result is x + 2)
-  long long out_off;       // c_{l-1} destination inside the plane workspace (non-final)
-  int hout, wout, ldout;
-  // final level only
-  const void* img;
-  long long img_plane_stride;
-  int H, W;
-  void* out;
-  long long out_plane_stride;
-  int out_dtype;            // 0 = uint16, 1 = float32
-  const float* flat;        // [hout][wout] or null
-  const float* dark;        // [dark_h][dark_ld] cropped to the plane, or null
-  int dark_ld;
-};
-
-constexpr int kInvTH = 32, kInvTW = 64;
-constexpr int kInvCR = kInvTH / 2 + 2, kInvCQ = kInvTW / 2 + 2;  // 18 x 34 coefficient tile
-
-__device__ __forceinline__ float finish_px(const InvArgs& a, float c0, float x, int gy, int gx) {
-  // exp(log(1 + x) + c0) + 1  (filtering.py:222: plus one, not minus)
-  float v = fmaf(1.0f + x, __expf(c0), 1.0f);
-  if (a.flat != nullptr) {  // flatfield_correction, filtering.py:399-412
-    const float d = a.dark[(long long)gy * a.dark_ld + gx];
-    v = (v > d) ? (v - d) : 0.f;
-    v = v / a.flat[(long long)gy * a.wout + gx];
-    v = fminf(fmaxf(v, 0.f), 65535.f);
-  }
-  return v;
-}
-
-// FINAL: 0 = pyramid level, 1 = last level with uint16 pixels, 2 = last level with float32 pixels
-template <int FINAL>
-__global__ __launch_bounds__(256) void k_idwt(InvArgs a) {
-  constexpr int TH = kInvTH, TW = kInvTW, CR = kInvCR, CQ = kInvCQ;
-  __shared__ float s_c[CR][CQ + 1], s_d[CR][CQ + 1];
-  __shared__ float s_a0[CR][TW], s_d0[CR][TW];
-  constexpr float RL[6] = DSX_REC_LO;
-  constexpr float RH[6] = DSX_REC_HI;
-  const int tid = threadIdx.x;
-  const int plane = blockIdx.z;
-  const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
-  const int p0 = y0 >> 1, q0 = x0 >> 1;
-  const float* cbuf = a.ws + plane * a.ws_plane_stride + a.c_off;
-  const float* dbuf = a.ws + plane * a.ws_plane_stride + a.d_off;
-
-  if (FINAL == 0 || a.has_pyr) {
-    for (int idx = tid; idx < CR * CQ; idx += 256) {
-      const int rr = idx / CQ, cc = idx - rr * CQ;
-      const int gp = p0 + rr, gq = q0 + cc;
-      const bool ok = (gp < a.hc) && (gq < a.wc);
-      s_c[rr][cc] = (ok && a.has_c) ? cbuf[(long long)gp * a.ldc + gq] : 0.f;
-      s_d[rr][cc] = ok ? dbuf[(long long)gp * a.ldc + gq] : 0.f;
-    }
-    __syncthreads();
-    // axis 1: out[2 q + b] = sum_j in[q + j] * rec_lo[4 - 2 j + b]   (ad = dd = 0: low-pass only)
-    for (int idx = tid; idx < CR * TW; idx += 256) {
-      const int rr = idx / TW, xx = idx - rr * TW;
-      const int qq = xx >> 1, b = xx & 1;
-      const float l0 = b ? RL[5] : RL[4], l1 = b ? RL[3] : RL[2], l2 = b ? RL[1] : RL[0];
-      s_a0[rr][xx] = fmaf(s_c[rr][qq], l0, fmaf(s_c[rr][qq + 1], l1, s_c[rr][qq + 2] * l2));
-      s_d0[rr][xx] = fmaf(s_d[rr][qq], l0, fmaf(s_d[rr][qq + 1], l1, s_d[rr][qq + 2] * l2));
-    }
-    __syncthreads();
-  }
-
-  for (int idx = tid; idx < TH * TW; idx += 256) {
-    const int yy = idx / TW, xx = idx - yy * TW;
-    const int gy = y0 + yy, gx = x0 + xx;
-    if (gy >= a.hout || gx >= a.wout) continue;
-    float v = 0.f;
-    if (FINAL == 0 || a.has_pyr) {
-      const int pp = yy >> 1, b = yy & 1;
-      const float l0 = b ? RL[5] : RL[4], l1 = b ? RL[3] : RL[2], l2 = b ? RL[1] : RL[0];
-      const float h0 = b ? RH[5] : RH[4], h1 = b ? RH[3] : RH[2], h2 = b ? RH[1] : RH[0];
-      v = s_a0[pp][xx] * l0;
-      v = fmaf(s_a0[pp + 1][xx], l1, v);
-      v = fmaf(s_a0[pp + 2][xx], l2, v);
-      v = fmaf(s_d0[pp][xx], h0, v);
-      v = fmaf(s_d0[pp + 1][xx], h1, v);
-      v = fmaf(s_d0[pp + 2][xx], h2, v);
-    }
-    if (FINAL == 0) {
-      a.ws[plane * a.ws_plane_stride + a.out_off + (long long)gy * a.ldout + gx] = v;
-    } else {
-      // an odd plane grows by one row/column: the reconstructed log image there is the
-      // half-sample symmetric extension, i.e. the replicated edge pixel
-      const int sy = min(gy, a.H - 1), sx = min(gx, a.W - 1);
-      float x;
-      if (FINAL == 1) {
-        x = (float)((const uint16_t*)a.img)[plane * a.img_plane_stride + (long long)sy * a.W + sx];
-      } else {
-        x = ((const float*)a.img)[plane * a.img_plane_stride + (long long)sy * a.W + sx];
-      }
-      const float r = finish_px(a, v, x, gy, gx);
-      const long long o = plane * a.out_plane_stride + (long long)gy * a.wout + gx;
-      if (a.out_dtype == 0) {
-        ((uint16_t*)a.out)[o] = (uint16_t)(int)fminf(fmaxf(r, 0.f), 65535.f);
-      } else {
-        ((float*)a.out)[o] = r;
-      }
-    }
-  }
-}
-
-// ================================================================================================
-// K5m/K6m: last synthesis level, "marching" form.  One wave owns 256 result columns (4 per lane)
+// K5/K6: synthesis level, "marching" form.  One wave owns 256 result columns (4 per lane)
 // and streams down the coefficient rows p: the row (axis-1) synthesis of c_1 / Delta_1 is done
 // in registers (3 taps), a 3-row register window feeds the column (axis-0) synthesis, and the
 // finish  (1 + x) exp(c0) + 1  (+ shading, cast) is fused.  No LDS, no barriers.
