@@ -241,7 +241,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     f.in_off = (l > 0) ? p.lv[l - 1].aa_off : 0;
     f.H = lp.hin; f.W = lp.win; f.ldin = lp.ldin;
     f.aa_off = lp.aa_off; f.da_off = lp.da_off;
-    f.h = lp.h; f.w = lp.w; f.ld = lp.ld;
+    f.h = lp.h; f.w = lp.w; f.ld = lp.ld; f.lda = lp.lda;
     f.minmax = v.minmax;
     f.lvl = l; f.L = L;
     f.stats = v.stats;
@@ -342,7 +342,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
       const dsx::LevelPlan& lp = p.lv[l];
       f.c_off = lp.aa_off;
       f.d_off = lp.da_off;
-      f.hc = lp.h; f.wc = lp.w; f.ldc = lp.ld;
+      f.hc = lp.h; f.wc = lp.w; f.ldc = lp.lda; f.ldd = lp.ld;
       f.has_c = (l < L - 1) ? 1 : 0;
       f.has_pyr = 1;
     }
@@ -351,7 +351,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
       const dsx::LevelPlan& lo = p.lv[l - 1];
       f.ws_out = v.ws;
       f.out_off = lo.aa_off;
-      f.hout = lo.h; f.wout = lo.w; f.ldout = lo.ld;
+      f.hout = lo.h; f.wout = lo.w; f.ldout = lo.lda;
     } else {
       f.img = d_in;
       f.img_plane_stride = (long long)p.H * p.W;
@@ -789,8 +789,9 @@ int dsx_get_level(dsx_ctx* ctx, int plane, int level, int stage, float* out) {
   DSX_HIP(hipStreamSynchronize(ctx->stream));
   const dsx::LevelPlan& lp = ctx->plan.lv[level];
   const long long off = (stage == DSX_STAGE_APPROX) ? lp.aa_off : lp.da_off;
+  const int pitch = (stage == DSX_STAGE_APPROX) ? lp.lda : lp.ld;
   const float* src = ctx->d_ws + (size_t)plane * ctx->plan.plane_floats + off;
-  DSX_HIP(hipMemcpy2D(out, sizeof(float) * lp.w, src, sizeof(float) * lp.ld, sizeof(float) * lp.w, lp.h,
+  DSX_HIP(hipMemcpy2D(out, sizeof(float) * lp.w, src, sizeof(float) * pitch, sizeof(float) * lp.w, lp.h,
                       hipMemcpyDeviceToHost));
   return DSX_OK;
 }

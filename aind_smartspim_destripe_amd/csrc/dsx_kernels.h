@@ -111,7 +111,7 @@ struct Fwd1Args {
   long long in_off;          // IN_KIND 2: offset of aa_{l-1} inside a plane's workspace
   int H, W, ldin;            // input rows, valid columns, row pitch (elements)
   long long aa_off, da_off;
-  int h, w, ld;
+  int h, w, ld, lda;  // coefficient shape, pitch of da, pitch of aa (with extension margins)
   unsigned* minmax;  // [B][L][2]
   int lvl, L;
   PlaneStats* stats;
@@ -158,7 +158,8 @@ struct MarchCol {
   int rc[4];  // reflected column per element (scalar path)
 };
 
-__device__ __forceinline__ MarchCol march_col(int gc0, int W, int ld, int w_out, bool lane_owns) {
+// ext: the source rows store the symmetric extension for columns [-4, W + 8) (aa_{l-1} buffers)
+__device__ __forceinline__ MarchCol march_col(int gc0, int W, int ld, int w_out, bool lane_owns, bool ext) {
   MarchCol c;
   c.gc0 = gc0;
   c.own = lane_owns;
@@ -167,7 +168,8 @@ __device__ __forceinline__ MarchCol march_col(int gc0, int W, int ld, int w_out,
   c.base = gc0;
   const bool aligned = (ld & 3) == 0;
   c.vec = aligned && gc0 >= 0 && gc0 + 3 < W;
-  if (!c.vec && aligned && (W & 3) == 0) {
+  if (ext && aligned && gc0 >= -4 && gc0 + 3 < W + 8) c.vec = true;
+  if (!c.vec && !ext && aligned && (W & 3) == 0) {
     // W % 4 == 0: a group never straddles the edge, the mirrored group is aligned as well
     if (gc0 + 3 < 0 && -gc0 - 1 < W) { c.base = -gc0 - 4; c.rev = true; c.vec = true; }
     else if (gc0 >= W && 2 * W - 4 - gc0 >= 0) { c.base = 2 * W - 4 - gc0; c.rev = true; c.vec = true; }
@@ -352,18 +354,30 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     if (out_lane) {
       const int j = j0 + jj0;
       const long long o = (long long)i * a.ld + j;
+      const long long oa = (long long)i * a.lda + j;
+      float* arow = aa + (long long)i * a.lda;
       if (j + 1 < a.w) {
-        *(float2*)(aa + o) = make_float2(res[0][0], res[0][1]);
+        *(float2*)(aa + oa) = make_float2(res[0][0], res[0][1]);
         *(float2*)(da + o) = make_float2(res[1][0], res[1][1]);
         const float q0 = res[1][0] * res[1][0], q1 = res[1][1] * res[1][1];
         qmin = fminf(qmin, fminf(q0, q1));
         qmax = fmaxf(qmax, fmaxf(q0, q1));
       } else if (j < a.w) {
-        aa[o] = res[0][0];
+        aa[oa] = res[0][0];
         da[o] = res[1][0];
         const float q0 = res[1][0] * res[1][0];
         qmin = fminf(qmin, q0);
         qmax = fmaxf(qmax, q0);
+      }
+      // half-sample symmetric extension of aa into the row margins: aa[-1-k] = aa[k] (k < 4),
+      // aa[w + k] = aa[w - 1 - k] (k < 8); read by the next level's aligned vector loads
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int je = j + e;
+        if (je < a.w) {
+          if (je < 4) arow[-1 - je] = res[0][e];
+          if (je >= a.w - 8) arow[2 * a.w - 1 - je] = res[0][e];
+        }
       }
     }
   };
@@ -428,7 +442,7 @@ __global__ __launch_bounds__(256) void k_fwd_march(Fwd1Args a) {
   const int plane = blockIdx.y;
   if (seg * a.rows_per_seg >= a.h) return;
   // lane 0 re-reads the last 4 columns of the previous strip and does not account them
-  const MarchCol col = march_col(2 * kMarchOut * strip - 4 + 4 * lane, a.W, a.ldin, a.w, lane >= 1);
+  const MarchCol col = march_col(2 * kMarchOut * strip - 4 + 4 * lane, a.W, a.ldin, a.w, lane >= 1, IN_KIND == 2);
   const bool all_vec = __all(col.vec || (col.dead && a.W >= 4 && (a.ldin & 3) == 0)) != 0;
   const bool any_rev = __any(col.rev) != 0;
   if (all_vec) fwd_march_body<IN_KIND, true>(a, s_row, lane, wave, strip, seg, plane, col, any_rev);
@@ -1019,7 +1033,7 @@ struct FinalArgs {
   const float* ws;
   long long ws_plane_stride;
   long long c_off, d_off;
-  int hc, wc, ldc;
+  int hc, wc, ldc, ldd;  // coefficient shape, pitch of c (aa buffer), pitch of Delta (da buffer)
   int has_c, has_pyr;
   const void* img;
   long long img_plane_stride;
@@ -1046,12 +1060,12 @@ struct FinalRawI {  // raw pixels x0 .. x0+3 of one plane row
   float4 f;
 };
 
-__device__ __forceinline__ void final_coeff_row(const FinalArgs& a, const float* base, int p, int q, bool on,
-                                                bool vec, float2& lo, float2& hi) {
+__device__ __forceinline__ void final_coeff_row(const FinalArgs& a, const float* base, int pitch, int p, int q,
+                                                bool on, bool vec, float2& lo, float2& hi) {
   lo = make_float2(0.f, 0.f);
   hi = make_float2(0.f, 0.f);
   if (!on || p >= a.hc) return;
-  const float* row = base + (long long)p * a.ldc;
+  const float* row = base + (long long)p * pitch;
   if (vec) {
     lo = *(const float2*)(row + q);
     hi = *(const float2*)(row + q + 2);
@@ -1108,24 +1122,28 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
   const bool vec_c = q + 3 < a.wc;
   const bool vec_in = (IN_KIND != 2) && ((a.W & 3) == 0) && (x0 + 3 < a.W);
   const int out_pitch = (IN_KIND == 2) ? a.ldout : a.wout;
-  const bool vec_out = ((out_pitch & 3) == 0) && (x0 + 3 < a.wout);
+  // pyramid levels write into padded aa rows: a 16-byte store may run into the margin columns
+  const bool vec_out = ((out_pitch & 3) == 0) && ((IN_KIND == 2) ? (x0 + 3 < a.wout + 8) : (x0 + 3 < a.wout));
   const long long img_plane = plane * a.img_plane_stride;
 
   auto issue_c = [&](int p) {
     FinalRawC r;
     if (FAST) {
-      const long long ro = (long long)min(p, a.hc - 1) * a.ldc + q;
+      // rows are padded (>= 4 spare columns): coefficients past the end only feed discarded results
+      const int pr = min(p, a.hc - 1);
       r.c01 = r.c23 = make_float2(0.f, 0.f);
       if (has_c) {  // uniform: the coarsest level has no approximation correction
-        r.c01 = *(const float2*)(cbase + ro);
-        r.c23 = *(const float2*)(cbase + ro + 2);
+        const long long rc = (long long)pr * a.ldc + q;
+        r.c01 = *(const float2*)(cbase + rc);
+        r.c23 = *(const float2*)(cbase + rc + 2);
       }
-      r.d01 = *(const float2*)(dbase + ro);
-      r.d23 = *(const float2*)(dbase + ro + 2);
+      const long long rd = (long long)pr * a.ldd + q;
+      r.d01 = *(const float2*)(dbase + rd);
+      r.d23 = *(const float2*)(dbase + rd + 2);
       return r;
     }
-    final_coeff_row(a, cbase, p, q, has_c, vec_c, r.c01, r.c23);
-    final_coeff_row(a, dbase, p, q, pyr, vec_c, r.d01, r.d23);
+    final_coeff_row(a, cbase, a.ldc, p, q, has_c, vec_c, r.c01, r.c23);
+    final_coeff_row(a, dbase, a.ldd, p, q, pyr, vec_c, r.d01, r.d23);
     return r;
   };
   auto issue_i = [&](int gy) {
@@ -1269,7 +1287,8 @@ __global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
   if (seg * a.rows_per_seg >= ((a.hout + 1) >> 1)) return;
   const int x0 = kMarchCols * strip + 4 * lane;
   if (x0 >= a.wout) return;
-  const bool lane_fast = (a.has_pyr != 0) && ((x0 >> 1) + 3 < a.wc) && ((a.ldc & 1) == 0) &&
+  // coefficient rows are padded, so every lane can load 4 coefficients; pixel rows are not
+  const bool lane_fast = (a.has_pyr != 0) && ((a.ldc & 1) == 0) && ((a.ldd & 1) == 0) &&
                          (IN_KIND == 2 || (((a.W & 3) == 0) && (x0 + 3 < a.W)));
   if (__all(lane_fast)) inv_march_body<IN_KIND, true>(a, lane, strip, seg, plane);
   else inv_march_body<IN_KIND, false>(a, lane, strip, seg, plane);

@@ -35,7 +35,8 @@ struct C32 {
 
 struct LevelPlan {
   int hin, win, ldin;  // input of the analysis level (level 0: the plane itself)
-  int h, w, ld;        // coefficient shape and row pitch (multiple of 4 floats)
+  int h, w, ld;        // coefficient shape and row pitch of da (multiple of 4 floats, >= w + 4)
+  int lda;             // row pitch of aa: 4 margin columns left + w + 8 right (symmetric extension)
   long long aa_off, da_off;
   // row filter
   int M, K;
@@ -187,10 +188,14 @@ inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p) {
     lp.hin = hin; lp.win = win; lp.ldin = ldin;
     lp.h = (hin + kFilterLen - 1) / 2;
     lp.w = (win + kFilterLen - 1) / 2;
-    lp.ld = (lp.w + 3) & ~3;
-    lp.aa_off = off; off += (long long)lp.h * lp.ld;
-    lp.da_off = off; off += (long long)lp.h * lp.ld;
-    hin = lp.h; win = lp.w; ldin = lp.ld;
+    // da rows: >= 4 spare columns so that the synthesis kernels may load 4 coefficients past the end;
+    // aa rows: logical column j lives at aa_off + i * lda + j, j in [-4, w + 8): the analysis kernel
+    // stores the half-sample symmetric extension there, so the next level loads aligned groups only
+    lp.ld = (lp.w + 4 + 3) & ~3;
+    lp.lda = (lp.w + 12 + 3) & ~3;
+    lp.aa_off = off + 4; off += (long long)lp.h * lp.lda + 8;
+    lp.da_off = off; off += (long long)lp.h * lp.ld + 8;
+    hin = lp.h; win = lp.w; ldin = lp.lda;
 
     // ---- row filter plan for this level -----------------------------------------------------
     const int n = lp.w;
