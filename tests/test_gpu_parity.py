@@ -303,3 +303,51 @@ def test_mixed_levels_between_configs(engine):
     for k in range(2):
         ref = orc.filter_stripes(planes[k], "t", nocells, cells, None, synth.ZARR_PATH_HIGH_INT)
         assert _rel(out[k], ref).max() < REL_TOL, (k, int(cfg[k]))
+
+
+def test_mask_flip_accounting_2048(engine):
+    """Hard decisions on full-size planes: per level, the number of masked coefficients (Delta == 0
+    marks a masked one) may differ from the float64 oracle only by the handful of coefficients that
+    sit within float32 round-off of the threshold."""
+    planes = synth.synthetic_bank(2, 2048, 2048, first=1)
+    engine.plan(2048, 2048, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT, max_batch=2)
+    engine.set_stop_after(2)
+    try:
+        engine.run(planes, out_dtype=np.float32)
+        for k in range(2):
+            _, _, _, _, stages = _oracle_plane(planes[k])
+            for lv, st in enumerate(stages):
+                delta = engine.level_array(k, lv, eng_mod.STAGE_DETAIL)
+                mask_ref = np.abs(st["ch"]) > st["threshold"]
+                mask_gpu = delta == 0.0
+                # an unmasked coefficient has Delta == 0 only by coincidence: count disagreements both ways
+                flips = int((mask_gpu != mask_ref).sum())
+                assert flips <= max(3, int(2e-5 * mask_ref.size)), (k, lv, flips, int(mask_ref.sum()))
+                otsu, thr = engine.thresholds(k, lv)
+                assert abs(thr - st["threshold"]) <= 2e-5 * max(st["threshold"], 1e-3)
+    finally:
+        engine.set_stop_after(0)
+
+
+def test_float32_input_2048_and_properties():
+    """Zarr-path dtype (float32 planes holding integers) at full size, plus size-independent properties:
+    float32 and uint16 planes with the same pixels give bit-identical results, and a constant plane has
+    nothing to filter (result x + 2)."""
+    planes = synth.synthetic_bank(2, 2048, 2048).astype(np.float32)
+    out, cfg = filtering.destripe_planes(planes, "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
+                                         synth.ZARR_PATH_HIGH_INT, out_dtype=np.float32, return_config=True,
+                                         max_batch=2)  # fmt: skip
+    out_u = filtering.destripe_planes(planes.astype(np.uint16), "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
+                                      synth.ZARR_PATH_HIGH_INT, out_dtype=np.float32, max_batch=2)  # fmt: skip
+    np.testing.assert_array_equal(out, out_u)  # same pixels, same arithmetic on the device
+    for k in range(2):
+        ref = orc.filter_stripes(planes[k], "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
+                                 synth.ZARR_PATH_HIGH_INT)  # fmt: skip
+        _assert_close(out[k], ref, ("f32-2048", k))
+    const = np.full((1, 2048, 2048), 777, np.uint16)
+    res = filtering.destripe_planes(const, "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
+                                    synth.ZARR_PATH_HIGH_INT, out_dtype=np.float32, max_batch=1)  # fmt: skip
+    assert np.abs(res - 779.0).max() < 779.0 * 2e-5
+    res_u = filtering.destripe_planes(const, "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
+                                      synth.ZARR_PATH_HIGH_INT, out_dtype=np.uint16, max_batch=1)  # fmt: skip
+    assert int(np.abs(res_u.astype(np.int64) - 779).max()) <= 1
