@@ -192,7 +192,7 @@ hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStre
 // Row segmentation of the marching kernels: enough waves to fill the chip for small cohorts,
 // one segment per strip for large ones (each extra segment re-reads a 4-row halo).
 void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg) {
-  const int target_waves = 256 * 16;
+  static const int target_waves = getenv("DSX_MARCH_WAVES") ? atoi(getenv("DSX_MARCH_WAVES")) : 256 * 16;
   int want = (target_waves + nb * nstrips - 1) / (nb * nstrips);
   const int max_seg = std::max(1, rows / 24);
   want = std::max(1, std::min(want, max_seg));
@@ -274,7 +274,8 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.minmax = v.minmax;
     a.hist = v.hist;
     a.lvl = l; a.L = L;
-    a.rows_per_block = 32;
+    static const int hist_rows = getenv("DSX_HIST_ROWS") ? atoi(getenv("DSX_HIST_ROWS")) : 32;
+    a.rows_per_block = hist_rows;
     dim3 grid((lp.h + a.rows_per_block - 1) / a.rows_per_block, nb);
     LaunchScope ls(ctx, KC_HIST);
     hipLaunchKernelGGL(dsx::k_hist, grid, dim3(256), 0, s, a);

@@ -1088,12 +1088,12 @@ __device__ __forceinline__ void final_xsynth(float2 lo, float2 hi, float (&o)[4]
 }
 
 // c0l = c0 * log2(e) (the factor is folded into the axis-0 synthesis taps of the last level)
-__device__ __forceinline__ float final_px(const FinalArgs& a, float c0l, float x, int gy, int gx) {
+template <bool SHADE>
+__device__ __forceinline__ float final_px(const FinalArgs& a, float c0l, float x, float dark, float flat) {
   float v = fmaf(1.0f + x, __builtin_amdgcn_exp2f(c0l), 1.0f);  // exp(log(1 + x) + c0) + 1  (filtering.py:222)
-  if (a.flat != nullptr) {                     // flatfield_correction, filtering.py:399-412
-    const float d = a.dark[(long long)gy * a.dark_ld + gx];
-    v = (v > d) ? (v - d) : 0.f;
-    v = v / a.flat[(long long)gy * a.wout + gx];
+  if (SHADE) {                                                    // flatfield_correction, filtering.py:399-412
+    v = (v > dark) ? (v - dark) : 0.f;
+    v = v / flat;
     v = fminf(fmaxf(v, 0.f), 65535.f);
   }
   return v;
@@ -1102,7 +1102,7 @@ __device__ __forceinline__ float final_px(const FinalArgs& a, float c0l, float x
 // Body of k_inv_march for one wave.  FAST: every lane loads its coefficients / pixels with aligned
 // vector loads, unconditionally (row indices are clamped: rows past the end only feed result rows
 // that are never stored) -- see fwd_march_body for why this is a separate instantiation.
-template <int IN_KIND, bool FAST>
+template <int IN_KIND, bool FAST, bool SHADE>
 __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int strip, int seg, int plane) {
   constexpr float RL0[6] = DSX_REC_LO;
   constexpr float RH0[6] = DSX_REC_HI;
@@ -1197,9 +1197,18 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
         px[e] = (IN_KIND == 0) ? (float)((const uint16_t*)a.img)[off] : ((const float*)a.img)[off];
       }
     }
+    float dk[4] = {0.f, 0.f, 0.f, 0.f}, fl[4] = {1.f, 1.f, 1.f, 1.f};
+    if (SHADE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int gx = min(x0 + e, a.wout - 1);
+        dk[e] = a.dark[(long long)gy * a.dark_ld + gx];
+        fl[e] = a.flat[(long long)gy * a.wout + gx];
+      }
+    }
     float r[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = (x0 + e < a.wout) ? final_px(a, c0[e], px[e], gy, x0 + e) : 0.f;
+    for (int e = 0; e < 4; ++e) r[e] = final_px<SHADE>(a, c0[e], px[e], dk[e], fl[e]);  // all four: stores are masked
     const long long o = plane * a.out_plane_stride + (long long)gy * a.wout + x0;
     if (a.out_dtype == 0) {
       unsigned u[4];
@@ -1290,8 +1299,14 @@ __global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
   // coefficient rows are padded, so every lane can load 4 coefficients; pixel rows are not
   const bool lane_fast = (a.has_pyr != 0) && ((a.ldc & 1) == 0) && ((a.ldd & 1) == 0) &&
                          (IN_KIND == 2 || (((a.W & 3) == 0) && (x0 + 3 < a.W)));
-  if (__all(lane_fast)) inv_march_body<IN_KIND, true>(a, lane, strip, seg, plane);
-  else inv_march_body<IN_KIND, false>(a, lane, strip, seg, plane);
+  const bool fast = __all(lane_fast) != 0;
+  if (IN_KIND != 2 && a.flat != nullptr) {
+    if (fast) inv_march_body<IN_KIND, true, IN_KIND != 2>(a, lane, strip, seg, plane);
+    else inv_march_body<IN_KIND, false, IN_KIND != 2>(a, lane, strip, seg, plane);
+  } else {
+    if (fast) inv_march_body<IN_KIND, true, false>(a, lane, strip, seg, plane);
+    else inv_march_body<IN_KIND, false, false>(a, lane, strip, seg, plane);
+  }
 }
 
 }  // namespace dsx
