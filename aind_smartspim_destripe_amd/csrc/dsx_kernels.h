@@ -310,6 +310,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   float qmin = __builtin_huge_valf(), qmax = 0.f;
   const int jj0 = 2 * lane;  // this lane's two output columns (lanes 0..62)
   const bool out_lane = lane < kMarchOut / 2;
+  const bool edge_strip = (j0 == 0) || (j0 + kMarchOut >= a.w - 8);
 
   // One output row i: the raw rows 2i, 2i+1 become window slots (r4, r5); r0..r5 = oldest..newest.
   auto step = [&](int i, const MarchRaw& raw0, const MarchRaw& raw1, float (&r0)[4], float (&r1)[4],
@@ -371,12 +372,14 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
       }
       // half-sample symmetric extension of aa into the row margins: aa[-1-k] = aa[k] (k < 4),
       // aa[w + k] = aa[w - 1 - k] (k < 8); read by the next level's aligned vector loads
+      if (edge_strip) {  // wave-uniform: only the first / last strips own margin columns
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int je = j + e;
-        if (je < a.w) {
-          if (je < 4) arow[-1 - je] = res[0][e];
-          if (je >= a.w - 8) arow[2 * a.w - 1 - je] = res[0][e];
+        for (int e = 0; e < 2; ++e) {
+          const int je = j + e;
+          if (je < a.w) {
+            if (je < 4) arow[-1 - je] = res[0][e];
+            if (je >= a.w - 8) arow[2 * a.w - 1 - je] = res[0][e];
+          }
         }
       }
     }
