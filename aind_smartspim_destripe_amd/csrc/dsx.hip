@@ -172,7 +172,8 @@ hipError_t launch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream
     if (e != hipSuccess) return e;
     attr_set[dev & 63] = true;
   }
-  const int wpb = (CPL > 18) ? 4 : rowfilter_waves_per_block(a.M);
+  static const int force_wpb = getenv("DSX_ROW_WPB") ? atoi(getenv("DSX_ROW_WPB")) : 0;
+  const int wpb = force_wpb ? force_wpb : ((CPL > 18) ? 4 : rowfilter_waves_per_block(a.M));
   const size_t smem = (size_t)a.M * (wpb + 1) * sizeof(float2);
   dim3 grid((npairs + wpb - 1) / wpb, nb);
   hipLaunchKernelGGL(dsx::k_rowfilter<CPL>, grid, dim3(64 * wpb), smem, s, a);

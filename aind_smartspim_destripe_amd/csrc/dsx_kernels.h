@@ -784,23 +784,22 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   const int M = a.M, N = a.w, K = a.K;
   float2* s_tw = dsx_smem;
   float2* buf = dsx_smem + (long long)M * (1 + wave);
-  for (int i = tid; i < M; i += blockDim.x) s_tw[i] = a.tw[i];
-  __syncthreads();  // the only block-wide barrier: afterwards every wave works on its own rows
-
   const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
   const int npairs = (a.h + 1) >> 1;
-  if (pair >= npairs) return;
+  const bool live = pair < npairs;  // (waves past the last pair still help loading the twiddles)
   const int plane = blockIdx.y;
-  const int r0 = 2 * pair;
+  const int r0 = live ? 2 * pair : 0;
   const bool has_b = (r0 + 1) < a.h;
   const int cfg = a.cfg[plane];
   float* rowa = a.ws + plane * a.ws_plane_stride + a.da_off + (long long)r0 * a.ld;
   float* rowb = rowa + a.ld;
 
-  if (a.lvl >= a.lvl_active[cfg]) {  // this config does not filter this level: Delta = 0
-    for (int n = 4 * lane; n < N; n += 4 * kWave) {
-      *(float4*)(rowa + n) = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (has_b) *(float4*)(rowb + n) = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.lvl >= a.lvl_active[cfg]) {  // this config does not filter this level: Delta = 0 (block-uniform)
+    if (live) {
+      for (int n = 4 * lane; n < N; n += 4 * kWave) {
+        *(float4*)(rowa + n) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_b) *(float4*)(rowb + n) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     return;
   }
@@ -813,20 +812,29 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   // hs = high halves, ls = low halves, both in signed order (^ 0x8000) for the saturating compare.
   constexpr int G = (CPL + 3) / 4;
   constexpr int E = 4 * G;
+  // issue the row loads, THEN stage the twiddles: the two global latencies overlap
+  float4 ra4[G], rb4[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int nb0 = 256 * g + 4 * lane;
+    ra4[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    rb4[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && nb0 < N) {  // nb0 + 3 < ld: the pitch is N rounded up to a multiple of 4 (plus spare)
+      ra4[g] = *(const float4*)(rowa + nb0);
+      if (has_b) rb4[g] = *(const float4*)(rowb + nb0);
+    }
+  }
+  for (int i = tid; i < M; i += blockDim.x) s_tw[i] = a.tw[i];
+  __syncthreads();  // the only block-wide barrier: afterwards every wave works on its own rows
+  if (!live) return;
+
   unsigned hs[E], ls[E];
   unsigned long long maska = 0, maskb = 0;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const int nb0 = 256 * g + 4 * lane;
-    float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (nb0 < N) {  // nb0 + 3 < ld: the pitch is N rounded up to a multiple of 4
-      const float4 fa = *(const float4*)(rowa + nb0);
-      va[0] = fa.x; va[1] = fa.y; va[2] = fa.z; va[3] = fa.w;
-      if (has_b) {
-        const float4 fb = *(const float4*)(rowb + nb0);
-        vb[0] = fb.x; vb[1] = fb.y; vb[2] = fb.z; vb[3] = fb.w;
-      }
-    }
+    const float va[4] = {ra4[g].x, ra4[g].y, ra4[g].z, ra4[g].w};
+    const float vb[4] = {rb4[g].x, rb4[g].y, rb4[g].z, rb4[g].w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = 4 * g + i;

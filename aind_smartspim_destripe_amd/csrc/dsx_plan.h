@@ -85,6 +85,14 @@ inline std::vector<int> factorize(int n) {
   for (int p = 7; n > 1; p += 2) {
     while (n % p == 0) { r.push_back(p); n /= p; }
   }
+  // Pass order = LDS bank behaviour: the first pass scatters with stride R (buf[R b + k]) and gathers
+  // twiddles tw[b k]; a power-of-two R puts whole lane groups on one bank (16-way conflicts for
+  // R = 16).  Radices with an odd factor go first, pure powers of two last (their stride is then
+  // multiplied by the odd product of the earlier passes).
+  std::stable_sort(r.begin(), r.end(), [](int a, int b) {
+    const bool pa = (a & (a - 1)) == 0, pb = (b & (b - 1)) == 0;
+    return !pa && pb;
+  });
   return r;
 }
 
