@@ -15,6 +15,7 @@
 
 #include "../../include/dsx.h"
 #include "dsx_kernels.h"
+#include "dsx_retile.h"
 #include "dsx_plan.h"
 
 namespace {
@@ -746,6 +747,78 @@ int dsx_profile_read(dsx_ctx* ctx, int max_classes, float* ms, int32_t* launches
     if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess && r.cls < nc) { ms[r.cls] += t; launches[r.cls]++; }
   }
   *n_classes = nc;
+  return DSX_OK;
+}
+
+/* ---- f1 / f3: Zarr brick re-tiling and the 2x2x2 pyramid level (dsx_retile.h) --------------- */
+namespace {
+int retile_vec(const void* a, const void* b, int W, int cx) {
+  int v = 8;
+  while (v > 1 && (W % v || cx % v || (uintptr_t)a % (2 * v) || (uintptr_t)b % (2 * v))) v >>= 1;
+  return v;
+}
+int brick_args(dsx_ctx* ctx, dsx::BrickArgs& a, int Z, int H, int W, int cz, int cy, int cx, int z0) {
+  if (Z <= 0 || H <= 0 || W <= 0 || cz <= 0 || cy <= 0 || cx <= 0 || z0 < 0)
+    return fail(ctx, DSX_EINVAL, "brick re-tiling: shapes must be positive");
+  a.Z = Z; a.H = H; a.W = W; a.cz = cz; a.cy = cy; a.cx = cx; a.z0 = z0;
+  a.nbz = (z0 + Z + cz - 1) / cz; a.nby = (H + cy - 1) / cy; a.nbx = (W + cx - 1) / cx;
+  if ((long long)a.nby * cy > 65535 || (long long)a.nbz * cz > 65535)
+    return fail(ctx, DSX_ELIMIT, "brick re-tiling: more than 65535 rows or planes per call");
+  return DSX_OK;
+}
+}  // namespace
+
+int dsx_bricks_to_planes_u16(dsx_ctx* ctx, const void* d_bricks, void* d_planes, int Z, int H, int W, int cz,
+                             int cy, int cx, int z0) {
+  if (!ctx || !d_bricks || !d_planes) return DSX_EINVAL;
+  dsx::BrickArgs a;
+  if (int rc = brick_args(ctx, a, Z, H, W, cz, cy, cx, z0)) return rc;
+  a.src = (const uint16_t*)d_bricks; a.dst = (uint16_t*)d_planes;
+  DSX_HIP(hipSetDevice(ctx->device));
+  const int v = retile_vec(d_bricks, d_planes, W, cx);
+  const dim3 grid((W / v + 255) / 256, H, Z);
+  switch (v) {
+    case 8: hipLaunchKernelGGL(dsx::k_bricks_to_planes<8>, grid, dim3(256), 0, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL(dsx::k_bricks_to_planes<4>, grid, dim3(256), 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL(dsx::k_bricks_to_planes<2>, grid, dim3(256), 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL(dsx::k_bricks_to_planes<1>, grid, dim3(256), 0, ctx->stream, a); break;
+  }
+  DSX_HIP(hipGetLastError());
+  return DSX_OK;
+}
+
+int dsx_planes_to_bricks_u16(dsx_ctx* ctx, const void* d_planes, void* d_bricks, int Z, int H, int W, int cz,
+                             int cy, int cx, int z0) {
+  if (!ctx || !d_bricks || !d_planes) return DSX_EINVAL;
+  dsx::BrickArgs a;
+  if (int rc = brick_args(ctx, a, Z, H, W, cz, cy, cx, z0)) return rc;
+  a.src = (const uint16_t*)d_planes; a.dst = (uint16_t*)d_bricks;
+  DSX_HIP(hipSetDevice(ctx->device));
+  const int v = retile_vec(d_bricks, d_planes, W, cx);
+  const dim3 grid((a.nbx * cx / v + 255) / 256, a.nby * cy, a.nbz * cz);
+  switch (v) {
+    case 8: hipLaunchKernelGGL(dsx::k_planes_to_bricks<8>, grid, dim3(256), 0, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL(dsx::k_planes_to_bricks<4>, grid, dim3(256), 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL(dsx::k_planes_to_bricks<2>, grid, dim3(256), 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL(dsx::k_planes_to_bricks<1>, grid, dim3(256), 0, ctx->stream, a); break;
+  }
+  DSX_HIP(hipGetLastError());
+  return DSX_OK;
+}
+
+int dsx_downsample2_u16(dsx_ctx* ctx, const void* d_src, void* d_dst, int Z, int Y, int X) {
+  if (!ctx || !d_src || !d_dst) return DSX_EINVAL;
+  if (Z < 2 || Y < 2 || X < 2) return fail(ctx, DSX_EINVAL, "downsample: every axis needs at least 2 voxels");
+  dsx::DownArgs a;
+  a.src = (const uint16_t*)d_src; a.dst = (uint16_t*)d_dst;
+  a.Z = Z; a.Y = Y; a.X = X; a.Zo = Z / 2; a.Yo = Y / 2; a.Xo = X / 2;
+  if (a.Yo > 65535 || a.Zo > 65535) return fail(ctx, DSX_ELIMIT, "downsample: more than 65535 rows or planes");
+  DSX_HIP(hipSetDevice(ctx->device));
+  const dim3 grid(((a.Xo + 3) / 4 + 255) / 256, a.Yo, a.Zo);
+  const bool vec = X % 8 == 0 && (uintptr_t)d_src % 16 == 0 && (uintptr_t)d_dst % 8 == 0;
+  if (vec) hipLaunchKernelGGL(dsx::k_downsample2<true>, grid, dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(dsx::k_downsample2<false>, grid, dim3(256), 0, ctx->stream, a);
+  DSX_HIP(hipGetLastError());
   return DSX_OK;
 }
 

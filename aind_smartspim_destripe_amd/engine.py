@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = [
     "dsx_malloc", "dsx_free", "dsx_memcpy_h2d", "dsx_memcpy_d2h", "dsx_memcpy_d2d",
     "dsx_timer_start", "dsx_timer_stop", "dsx_profile_enable", "dsx_profile_read",
     "dsx_get_stats", "dsx_get_thresholds", "dsx_get_level", "dsx_set_stop_after",
+    "dsx_bricks_to_planes_u16", "dsx_planes_to_bricks_u16", "dsx_downsample2_u16",
 ]  # fmt: skip
 
 
@@ -109,6 +110,9 @@ def load_library(path=None):
     lib.dsx_get_thresholds.argtypes = [vp, i32, i32, f32p, f32p]
     lib.dsx_get_level.argtypes = [vp, i32, i32, i32, vp]
     lib.dsx_set_stop_after.argtypes = [vp, i32]
+    lib.dsx_bricks_to_planes_u16.argtypes = [vp, vp, vp] + [i32] * 7
+    lib.dsx_planes_to_bricks_u16.argtypes = [vp, vp, vp] + [i32] * 7
+    lib.dsx_downsample2_u16.argtypes = [vp, vp, vp, i32, i32, i32]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("dsx_destroy", "dsx_last_error"):
@@ -309,6 +313,27 @@ class DestripeEngine:
         n = ctypes.c_int()
         self._check(self._lib.dsx_profile_read(self._ctx, 16, ms, cnt, names, ctypes.byref(n)))
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+    # -- data formats either side of the filter (device buffers, asynchronous) -------------------
+    def bricks_to_planes(self, d_bricks, d_planes, zyx, brick, z0=0):
+        """Zarr chunk order -> dense ``[Z, H, W]`` uint16 (``zarr_destriper.py:1066-1074``)."""
+        self._check(self._lib.dsx_bricks_to_planes_u16(self._ctx, ctypes.c_void_p(d_bricks.ptr),
+                                                       ctypes.c_void_p(d_planes.ptr), *map(int, zyx),
+                                                       *map(int, brick), int(z0)))  # fmt: skip
+
+    def planes_to_bricks(self, d_planes, d_bricks, zyx, brick, z0=0):
+        """Dense ``[Z, H, W]`` uint16 -> Zarr chunk order, 0 outside the stack (``zarr_destriper.py:336``)."""
+        self._check(self._lib.dsx_planes_to_bricks_u16(self._ctx, ctypes.c_void_p(d_planes.ptr),
+                                                       ctypes.c_void_p(d_bricks.ptr), *map(int, zyx),
+                                                       *map(int, brick), int(z0)))  # fmt: skip
+
+    def downsample2(self, d_src, d_dst, zyx):
+        """One 2x2x2 windowed-mean pyramid level, uint16 (``zarr_destriper.py:365-407``)."""
+        rc = self._lib.dsx_downsample2_u16(self._ctx, ctypes.c_void_p(d_src.ptr), ctypes.c_void_p(d_dst.ptr),
+                                           *map(int, zyx))  # fmt: skip
+        if rc == -1:
+            raise ValueError(self._lib.dsx_last_error(self._ctx).decode())
+        self._check(rc)
 
     # -- parity hooks ----------------------------------------------------------------------------
     def set_stop_after(self, stage):

@@ -83,6 +83,22 @@ class MiniZarrArray:
             raw = zlib.decompress(raw)
         return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks).copy()
 
+    def read_chunk_into(self, idx, out_flat):
+        """Decompressed chunk ``idx`` (the whole brick, as stored) into a flat array of chunk size."""
+        p = self._chunk_path(idx)
+        if not os.path.exists(p):
+            out_flat[...] = self.fill_value
+            return
+        with open(p, "rb") as f:
+            raw = f.read()
+        if self.compressor is not None:
+            raw = zlib.decompress(raw)
+        out_flat[...] = np.frombuffer(raw, dtype=self.dtype)
+
+    def write_chunk_flat(self, idx, flat):
+        """Store a whole brick given in chunk (C) order."""
+        self._write_chunk(idx, np.asarray(flat, dtype=self.dtype))
+
     def _write_chunk(self, idx, block):
         p = self._chunk_path(idx)
         os.makedirs(os.path.dirname(p), exist_ok=True)

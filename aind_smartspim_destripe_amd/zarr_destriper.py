@@ -11,12 +11,19 @@ consumer process pool (``:797-906``) becomes a plain loop over z-blocks per rank
 ``aind_large_scale_prediction==1.0.0`` (``zarr_destriper.py:22-24``), which is not vendored in the
 reference and not installed here; their behaviour is restated from the call site (``:268-312``) and is
 exact for the production setting ``overlap_prediction_chunksize=(0, 0, 0)`` (``:1018-1022``).
-Out of scope here: OME-NGFF metadata, the multiscale pyramid, the psutil profiler.
+
+Row f1 of SURVEY section 8: when the store holds uint16 bricks, :func:`destripe_zarr` uploads the
+decompressed chunks as they lie in the store and re-tiles them into planes (and the filtered planes back
+into bricks) on the device (``dsx_bricks_to_planes_u16`` / ``dsx_planes_to_bricks_u16``), so the host only
+(de)compresses -- no NumPy gather / scatter of 128 x 128 tiles.  The multiscale pyramid is in ``pyramid.py``.
+Out of scope here: OME-NGFF metadata, the psutil profiler.
 """
 
+import itertools
 import logging
 import os
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -134,6 +141,64 @@ def iter_blocks(zyx_shape, prediction_chunksize, z_range=None):
                 yield sc, [internal]
 
 
+class _DeviceBlocks:
+    """Brick-order staging + device re-tiling for one rank (row f1)."""
+
+    def __init__(self, eng, src, dst, zyx, block_z, io_threads):
+        self.eng, self.src, self.dst, self.zyx = eng, src, dst, zyx
+        self.ci, self.co = tuple(src.chunks[-3:]), tuple(dst.chunks[-3:])
+        _, H, W = zyx
+        grid = lambda c, zspan: (-(-zspan // c[0]), -(-H // c[1]), -(-W // c[2]))  # noqa: E731
+        self.gi = grid(self.ci, block_z + self.ci[0] - 1)  # a block may start inside an input chunk
+        self.go = grid(self.co, block_z)
+        self.stage_in = np.empty(self.gi + (int(np.prod(self.ci)),), dtype=np.uint16)
+        self.out_brick = int(np.prod(self.co))
+        self.d_bricks_in = eng.alloc(self.stage_in.nbytes)
+        self.d_bricks_out = eng.alloc(int(np.prod(self.go)) * self.out_brick * 2)
+        self.d_planes = eng.alloc(block_z * H * W * 2)
+        self.d_out = eng.alloc(block_z * H * W * 2)
+        self.pool = ThreadPoolExecutor(max_workers=io_threads)
+
+    def close(self):
+        self.pool.shutdown()
+        for b in (self.d_bricks_in, self.d_bricks_out, self.d_planes, self.d_out):
+            b.free()
+
+    def run(self, z0, z1):
+        """Planes ``[z0, z1)``: read bricks -> HBM -> planes -> filter -> bricks -> store."""
+        eng, (_, H, W), Z = self.eng, self.zyx, z1 - z0
+        lead_i = (0,) * (self.src.ndim - 3)
+        lead_o = (0,) * (self.dst.ndim - 3)
+        bz0, zoff = divmod(z0, self.ci[0])
+        nbz = -(-(zoff + Z) // self.ci[0])
+        idx = list(itertools.product(range(nbz), range(self.gi[1]), range(self.gi[2])))
+        list(self.pool.map(lambda i: self.src.read_chunk_into(lead_i + (bz0 + i[0], i[1], i[2]), self.stage_in[i]), idx))
+        self.d_bricks_in.upload(self.stage_in[:nbz])
+        eng.bricks_to_planes(self.d_bricks_in, self.d_planes, (Z, H, W), self.ci, zoff)
+        eng.run_device(self.d_planes, np.uint16, Z, self.d_out, np.uint16, None)
+        eng.planes_to_bricks(self.d_out, self.d_bricks_out, (Z, H, W), self.co, 0)
+        nbo = -(-Z // self.co[0])
+        out = self.d_bricks_out.download((nbo,) + self.go[1:] + (self.out_brick,), np.uint16)
+        oz0 = z0 // self.co[0]
+        odx = list(itertools.product(range(nbo), range(self.go[1]), range(self.go[2])))
+        list(self.pool.map(lambda i: self.dst.write_chunk_flat(lead_o + (oz0 + i[0], i[1], i[2]),
+                                                               out[i].reshape(self.dst.chunks)), odx))  # fmt: skip
+
+
+def _device_retile_ok(src, dst, zyx, block_z, z0, z1):
+    """The device brick path needs uint16 bricks, even planes and output-chunk-aligned z blocks."""
+    co = dst.chunks[-3:]
+    return (
+        src.dtype == np.uint16
+        and all(c == 1 for c in src.chunks[:-3])
+        and zyx[1] % 2 == 0
+        and zyx[2] % 2 == 0
+        and block_z % co[0] == 0
+        and z0 % co[0] == 0
+        and (z1 % co[0] == 0 or z1 == zyx[0])
+    )
+
+
 def destripe_zarr(
     dataset_path,
     output_path,
@@ -147,6 +212,8 @@ def destripe_zarr(
     device=None,
     compressor=None,
     logger=None,
+    device_retile=None,
+    io_threads=8,
 ):
     """Chunk map of ``destripe_zarr`` (``zarr_destriper.py:909-1211``) over a Zarr-v2 directory store.
 
@@ -154,6 +221,10 @@ def destripe_zarr(
     (chunk-aligned, so no two ranks touch one output chunk).  Blocks cover the full Y x X plane in
     production (``prediction_chunksize=(64, 1600, 2000)`` == the tile, ``:1256``); smaller y/x blocks
     would change the result (the filter is per plane), so they are rejected.
+
+    ``device_retile``: ``True`` = chunks are re-tiled into planes and back on the GPU (row f1; needs a
+    uint16 store and chunk-aligned z blocks), ``False`` = host gather / scatter through
+    :func:`execute_worker`, ``None`` = the device path whenever it applies.
     """
     logger = logger or logging.getLogger("dsx.zarr")
     src = MiniZarrArray.open(dataset_path)
@@ -173,6 +244,25 @@ def destripe_zarr(
     dev = rank if device is None else device
     name = os.path.basename(str(dataset_path).rstrip("/"))
     n_planes, t0 = 0, time.perf_counter()
+    block_z = int(prediction_chunksize[0])
+    can = z1 > z0 and _device_retile_ok(src, dst, zyx, block_z, z0, z1)
+    if device_retile and not can:
+        raise ValueError("device_retile needs a uint16 store, even planes and output-chunk-aligned z blocks")
+    if can and device_retile is not False:
+        flatfield, darkfield = fl._resolve_shading(shadow_correction, name.replace(".zarr", ""))
+        eng = fl.get_engine(zyx[1:], cells_config, no_cells_config, 2500, flatfield, darkfield,
+                            max_batch=min(block_z, 64), device=dev)  # fmt: skip
+        blocks = _DeviceBlocks(eng, src, dst, zyx, block_z, io_threads)
+        try:
+            for z in range(z0, z1, block_z):
+                blocks.run(z, min(z + block_z, z1))
+                n_planes += min(z + block_z, z1) - z
+            eng.sync()
+        finally:
+            blocks.close()
+        dt = time.perf_counter() - t0
+        logger.info("rank %d: %d planes z[%d:%d) in %.2f s (device re-tiling)", rank, n_planes, z0, z1, dt)
+        return n_planes, dt
     for sc, internal in iter_blocks(zyx, prediction_chunksize, (z0, z1)):
         lead = (0,) * (len(src.shape) - 3)
         block = src[lead + sc]

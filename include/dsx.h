@@ -121,6 +121,23 @@ int dsx_profile_enable(dsx_ctx* ctx, int on);
 int dsx_profile_read(dsx_ctx* ctx, int max_classes, float* ms, int32_t* launches,
                      const char** names, int* n_classes);
 
+/* ---- data formats either side of the filter ------------- */
+/* Zarr chunk ("brick") order <-> dense planes, uint16, device pointers, asynchronous on the
+ * context stream.  Replaces the NumPy gather of (1,1,64,128,128) chunks into a block and the
+ * scatter of the filtered block back into chunks (zarr_destriper.py:1066-1074 and :336).
+ * d_bricks: [nbz][nby][nbx][cz][cy][cx], every brick full-sized as zarr stores it
+ * (nb* = ceil over the axis; nbz = ceil((z0 + Z) / cz)); d_planes: dense [Z][H][W]; z0: position
+ * of plane 0 inside the brick grid.  planes_to_bricks writes 0 (the fill value) where a brick
+ * sticks out of the stack.                                                                    */
+int dsx_bricks_to_planes_u16(dsx_ctx* ctx, const void* d_bricks, void* d_planes, int Z, int H,
+                             int W, int cz, int cy, int cx, int z0);
+int dsx_planes_to_bricks_u16(dsx_ctx* ctx, const void* d_planes, void* d_bricks, int Z, int H,
+                             int W, int cz, int cy, int cx, int z0);
+/* One 2x2x2 windowed-mean pyramid level, uint16 [Z,Y,X] -> [Z/2,Y/2,X/2] (odd trailing voxels are
+ * cropped), value = floor(sum of 8 / 8): compute_pyramid(), zarr_destriper.py:365-407, i.e.
+ * xarray_multiscale.reducers.windowed_mean + preserve_dtype.  Asynchronous on the context stream. */
+int dsx_downsample2_u16(dsx_ctx* ctx, const void* d_src, void* d_dst, int Z, int Y, int X);
+
 /* ---- parity / debug hooks (state of the LAST cohort of the last run) ----------------------- */
 /* Per plane of the last cohort: fore/back means and chosen config (filtering.py:459-462). */
 int dsx_get_stats(dsx_ctx* ctx, int plane, double* fore_mean, double* back_mean,

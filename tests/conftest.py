@@ -17,6 +17,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_library():
+    """Build libdsx_hip.so in-tree if it is not there (hipcc cross-compiles without a GPU)."""
+    lib = os.path.join(REPO, "aind_smartspim_destripe_amd", "_lib", "libdsx_hip.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+
+        g.build()
+    yield
+
+
 def _load(name):
     return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
 
