@@ -822,6 +822,24 @@ int dsx_downsample2_u16(dsx_ctx* ctx, const void* d_src, void* d_dst, int Z, int
   return DSX_OK;
 }
 
+int dsx_flatfield_correction(dsx_ctx* ctx, const void* d_img, int in_dtype, int H, int W, const float* d_flat,
+                             const float* d_dark, int dark_h, int dark_w, float baseline, void* d_out) {
+  if (!ctx || !d_img || !d_flat || !d_dark || !d_out) return DSX_EINVAL;
+  if (in_dtype != DSX_U16 && in_dtype != DSX_F32) return fail(ctx, DSX_EINVAL, "unknown element type");
+  if (H <= 0 || W <= 0 || H > 65535) return fail(ctx, DSX_EINVAL, "flatfield_correction: bad plane shape");
+  if (dark_h < H || dark_w < W)
+    return fail(ctx, DSX_EINVAL, "Please, check the shape of the darkfield (smaller than the image)");
+  dsx::ShadeArgs a;
+  a.src = d_img; a.flat = d_flat; a.dark = d_dark; a.dst = (uint16_t*)d_out;
+  a.H = H; a.W = W; a.dark_w = dark_w; a.baseline = baseline;
+  DSX_HIP(hipSetDevice(ctx->device));
+  const dim3 grid((W + 255) / 256, H);
+  if (in_dtype == DSX_U16) hipLaunchKernelGGL(dsx::k_shade<true>, grid, dim3(256), 0, ctx->stream, a);
+  else hipLaunchKernelGGL(dsx::k_shade<false>, grid, dim3(256), 0, ctx->stream, a);
+  DSX_HIP(hipGetLastError());
+  return DSX_OK;
+}
+
 /* ---- debug hooks ---------------------------------------------------------------------------- */
 int dsx_set_stop_after(dsx_ctx* ctx, int stage) {
   if (!ctx || stage < 0 || stage > 2) return DSX_EINVAL;

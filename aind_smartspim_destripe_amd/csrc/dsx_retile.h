@@ -116,4 +116,32 @@ __global__ __launch_bounds__(256) void k_downsample2(DownArgs a) {
   }
 }
 
+// ---- a11 as a stand-alone call: flatfield_correction() of one plane (filtering.py:338-414) ------------
+// x = x > dark ? x - dark : 0 (assigned back into the image, so integer planes truncate, :400-403);
+// x / flat - baseline; clip to [0, 65535]; truncate to uint16.  Inside the filter the same arithmetic
+// is fused into the last synthesis kernel; this kernel serves direct callers of the reference function.
+struct ShadeArgs {
+  const void* src;
+  const float* flat;
+  const float* dark;  // [dark_h][dark_w], cropped to the plane by indexing
+  uint16_t* dst;
+  int H, W, dark_w;
+  float baseline;
+};
+
+template <bool U16>
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= a.W) return;
+  const int y = blockIdx.y;
+  const size_t i = (size_t)y * a.W + x;
+  const float v = U16 ? (float)reinterpret_cast<const uint16_t*>(a.src)[i] : reinterpret_cast<const float*>(a.src)[i];
+  const float d = a.dark[(size_t)y * a.dark_w + x];
+  float t = v > d ? v - d : 0.f;
+  if (U16) t = truncf(t);
+  float c = t / a.flat[i] - a.baseline;
+  c = fminf(fmaxf(c, 0.f), 65535.f);
+  a.dst[i] = (uint16_t)c;
+}
+
 }  // namespace dsx

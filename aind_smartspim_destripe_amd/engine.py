@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "dsx_timer_start", "dsx_timer_stop", "dsx_profile_enable", "dsx_profile_read",
     "dsx_get_stats", "dsx_get_thresholds", "dsx_get_level", "dsx_set_stop_after",
     "dsx_bricks_to_planes_u16", "dsx_planes_to_bricks_u16", "dsx_downsample2_u16",
+    "dsx_flatfield_correction",
 ]  # fmt: skip
 
 
@@ -113,6 +114,7 @@ def load_library(path=None):
     lib.dsx_bricks_to_planes_u16.argtypes = [vp, vp, vp] + [i32] * 7
     lib.dsx_planes_to_bricks_u16.argtypes = [vp, vp, vp] + [i32] * 7
     lib.dsx_downsample2_u16.argtypes = [vp, vp, vp, i32, i32, i32]
+    lib.dsx_flatfield_correction.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, ctypes.c_float, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("dsx_destroy", "dsx_last_error"):
@@ -334,6 +336,28 @@ class DestripeEngine:
         if rc == -1:
             raise ValueError(self._lib.dsx_last_error(self._ctx).decode())
         self._check(rc)
+
+    def flatfield_correction(self, plane, flatfield, darkfield, baseline=0.0):
+        """One host plane (uint16 / float32) through ``dsx_flatfield_correction``; uint16 result."""
+        a = np.ascontiguousarray(plane)
+        flat = np.ascontiguousarray(flatfield, dtype=np.float32)
+        dark = np.ascontiguousarray(darkfield, dtype=np.float32)
+        H, W = a.shape
+        bufs = [self.alloc(max(x.nbytes, 16)) for x in (a, flat, dark)] + [self.alloc(max(H * W * 2, 16))]
+        try:
+            for b, x in zip(bufs, (a, flat, dark)):
+                b.upload(x)
+            rc = self._lib.dsx_flatfield_correction(self._ctx, ctypes.c_void_p(bufs[0].ptr), _dtype_code(a.dtype), H, W,
+                                                    ctypes.c_void_p(bufs[1].ptr), ctypes.c_void_p(bufs[2].ptr),
+                                                    dark.shape[0], dark.shape[1], float(baseline),
+                                                    ctypes.c_void_p(bufs[3].ptr))  # fmt: skip
+            if rc == -1:
+                raise ValueError(self._lib.dsx_last_error(self._ctx).decode())
+            self._check(rc)
+            return bufs[3].download((H, W), np.uint16)
+        finally:
+            for b in bufs:
+                b.free()
 
     # -- parity hooks ----------------------------------------------------------------------------
     def set_stop_after(self, stage):

@@ -102,12 +102,15 @@ def get_hemisphere_flatfield(input_tile_path, tile_config, flatfields, zarr=True
     return flatfields[brain_side]
 
 
-def flatfield_correction(image_tiles, flatfield, darkfield, baseline=None):
-    """``filtering.py:338-414`` as a stand-alone host helper (uint16 result).
+def flatfield_correction(image_tiles, flatfield, darkfield, baseline=None, device=0):
+    """``filtering.py:338-414`` as a stand-alone call on the GPU (``dsx_flatfield_correction``; uint16 result).
 
-    Inside :func:`filter_stripes` the same arithmetic is fused into the last GPU kernel.
+    Shape handling and errors follow the reference line by line (including its quirk that only one plane
+    passes the shape checks, ``:370-391``); the arithmetic runs in float32 on the device.  Inside
+    :func:`filter_stripes` the same arithmetic is fused into the last synthesis kernel.
     """
     image_tiles = np.array(image_tiles)
+    flatfield, darkfield = np.asarray(flatfield), np.asarray(darkfield)
     if image_tiles.ndim != flatfield.ndim:
         flatfield = np.expand_dims(flatfield, axis=0)
     if image_tiles.ndim != darkfield.ndim:
@@ -125,11 +128,24 @@ def flatfield_correction(image_tiles, flatfield, darkfield, baseline=None):
         )
     if baseline is None:
         baseline = np.zeros((image_tiles.shape[0],))
-    idx = tuple([slice(None)] + ([np.newaxis] * (image_tiles.ndim - 1)))
-    above = image_tiles > darkfield
-    tiles = np.where(above, image_tiles - darkfield, 0).astype(image_tiles.dtype)
-    corrected = tiles / flatfield - baseline[idx]
-    return np.clip(corrected, 0, 65535).astype("uint16")
+    baseline = np.asarray(baseline, dtype=np.float64).ravel()
+    plane_shape = image_tiles.shape[-2:]
+    if image_tiles.ndim < 2 or int(np.prod(image_tiles.shape[:-2])) != 1:
+        raise ValueError("flatfield_correction takes one plane ([H, W] or [1, H, W])")
+    # a 2-D plane broadcasts baseline[:, None] over its rows (:393-398); a constant is all the kernel takes
+    if baseline.size and not np.all(baseline == baseline[0]):
+        raise NotImplementedError("per-row baselines are not implemented (the reference only uses zeros)")
+    eng = next((e[0] for k, e in _ENGINES.items() if k[0] == device), None)
+    own = eng is None
+    if own:
+        eng = _engine.DestripeEngine(device)
+    try:
+        out = eng.flatfield_correction(_as_plane_dtype(image_tiles.reshape(plane_shape)), flatfield.reshape(plane_shape),
+                                       darkfield.reshape(plane_shape), float(baseline[0]) if baseline.size else 0.0)
+    finally:
+        if own:
+            eng.close()
+    return out.reshape(image_tiles.shape)
 
 
 # ---------------------------------------------------------------------------------------------

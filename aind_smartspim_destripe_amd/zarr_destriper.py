@@ -20,16 +20,118 @@ Out of scope here: OME-NGFF metadata, the psutil profiler.
 """
 
 import itertools
+import json
 import logging
 import os
+import re
 import time
 from concurrent.futures import ThreadPoolExecutor
+from glob import glob
+from pathlib import Path
 
 import numpy as np
 
 from . import filtering as fl
 from .distributed import z_shard
+from . import mini_tiff as tif
 from .mini_zarr import MiniZarrArray
+
+
+# ---------------------------------------------------------------------------------------------
+# Shading plumbing around the filter
+# ---------------------------------------------------------------------------------------------
+def read_json_as_dict(filepath: str) -> dict:
+    """``utils/utils.py:414-446``: ``{}`` for a missing file; a second, lossy decode on ``UnicodeDecodeError``."""
+    dictionary = {}
+    if os.path.exists(filepath):
+        try:
+            with open(filepath) as json_file:
+                dictionary = json.load(json_file)
+        except UnicodeDecodeError:
+            print("Error reading json with utf-8, trying different approach")
+            with open(filepath, "rb") as json_file:
+                data = json_file.read()
+                dictionary = json.loads(data.decode("utf-8", errors="ignore"))
+    return dictionary
+
+
+def _natsorted(names):
+    """Natural order of file names (``natsort.natsorted`` default: digit runs compare as integers)."""
+    key = lambda s: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", str(s))]  # noqa: E731
+    return sorted(names, key=key)
+
+
+def get_microscope_flats(channel_name: str, derivatives_folder):
+    """``zarr_destriper.py:70-154``: the two ``FlatReal<wavelength>_*.tif`` planes of a channel (one per brain
+    hemisphere) and ``{X folder: {Y folder: side}}`` from ``metadata.json``.
+
+    ``(None, None)`` when there is no ``metadata.json`` or the channel name holds no wavelength;
+    ``ValueError`` without ``tile_config`` or when the number of flats is not 2; ``KeyError`` for a tile
+    entry without ``X`` / ``Y`` / ``Side``.
+    """
+    flatfield = None
+    metadata_json = None
+    derivatives_folder = Path(derivatives_folder)
+    waves = [p for p in str(channel_name).split("_") if p.isdigit()]
+    metadata_json_path = derivatives_folder.joinpath("metadata.json")
+    if metadata_json_path.exists() and len(waves):
+        orig_metadata_json = read_json_as_dict(filepath=metadata_json_path)
+        curr_emision_wave = int(waves[0])
+        tile_config = orig_metadata_json.get("tile_config")
+        metadata_json = {}
+        if tile_config is None:
+            raise ValueError("Please, verify metadata.json")
+        for time_step, value in tile_config.items():
+            if int(value.get("Laser")) == curr_emision_wave:
+                x_folder, y_folder, brain_side = value.get("X"), value.get("Y"), value.get("Side")
+                if x_folder is None or y_folder is None or brain_side is None:
+                    raise KeyError("Please, check the data in metadata.json")
+                if metadata_json.get(x_folder) is None:
+                    metadata_json[x_folder] = {}
+                metadata_json[x_folder][y_folder] = int(brain_side)
+        flatfield = [
+            tif.imread(g)
+            for g in _natsorted(glob(f"{derivatives_folder}/FlatReal{curr_emision_wave}_*.tif"))
+            if os.path.exists(g)
+        ]
+        if len(flatfield) != 2:
+            raise ValueError(f"Error while reading the microscope flatfields: {flatfield}")
+    return flatfield, metadata_json
+
+
+def load_shadow_correction(derivatives_path, output_destriped_zarr, flatfield=None, logger=None):
+    """The ``shadow_correction`` dict exactly as ``destripe_zarr`` assembles it (``zarr_destriper.py:1095-1130``):
+    the microscope dark (``DarkMaster_cropped.tif``, ``FileNotFoundError`` if absent), and either the given
+    retrospective flat or the normalised microscope flats with their tile config.
+    """
+    logger = logger or logging.getLogger("dsx.zarr")
+    derivatives_path = Path(derivatives_path)
+    darkfield = None
+    tile_config = None
+    retrospective = False if flatfield is None else True
+    if os.path.exists(derivatives_path):
+        darkfield_path = str(derivatives_path.joinpath("DarkMaster_cropped.tif"))
+        logger.info(f"Loading darkfield from path: {darkfield_path}")
+        try:
+            darkfield = tif.imread(darkfield_path)
+        except FileNotFoundError:
+            raise FileNotFoundError(
+                f"Please, provide the current dark from the microscope! Provided path: {darkfield_path}"
+            )
+        if flatfield is None:
+            channel_name = Path(output_destriped_zarr).parent.name
+            flatfield, tile_config = get_microscope_flats(
+                channel_name=str(channel_name), derivatives_folder=derivatives_path
+            )
+            flatfield = fl.normalize_image(flatfield)
+        else:
+            logger.info("Ignoring microscope flats...")
+    return {
+        "retrospective": retrospective,
+        "flatfield": flatfield,
+        "darkfield": darkfield,
+        "tile_config": tile_config,
+    }
 
 
 def pad_array_n_d(arr, dim: int = 5):
@@ -214,6 +316,7 @@ def destripe_zarr(
     logger=None,
     device_retile=None,
     io_threads=8,
+    tile_name=None,
 ):
     """Chunk map of ``destripe_zarr`` (``zarr_destriper.py:909-1211``) over a Zarr-v2 directory store.
 
@@ -242,7 +345,8 @@ def destripe_zarr(
     dst = MiniZarrArray.open(output_path)
     z0, z1 = z_shard(zyx[0], world_size, rank, z_chunk=output_chunks[-3])
     dev = rank if device is None else device
-    name = os.path.basename(str(dataset_path).rstrip("/"))
+    # dataset_name of the reference = the tile folder (X_..._Y_....zarr), also when level "0" is opened
+    name = tile_name or os.path.basename(str(dataset_path).rstrip("/"))
     n_planes, t0 = 0, time.perf_counter()
     block_z = int(prediction_chunksize[0])
     can = z1 > z0 and _device_retile_ok(src, dst, zyx, block_z, z0, z1)
@@ -273,3 +377,74 @@ def destripe_zarr(
     dt = time.perf_counter() - t0
     logger.info("rank %d: %d planes z[%d:%d) in %.2f s", rank, n_planes, z0, z1, dt)
     return n_planes, dt
+
+
+def destripe_channel(
+    zarr_dataset_path,
+    derivatives_path,
+    channel_name,
+    results_folder,
+    estimated_channel_flats,
+    laser_tiles,
+    parameters,
+    multiscale="0",
+    prediction_chunksize=(64, 1600, 2000),
+    output_chunks=(1, 1, 64, 128, 128),
+    rank=0,
+    world_size=1,
+    device=None,
+    compressor=None,
+    n_levels=3,
+    logger=None,
+):
+    """Tile loop of ``destripe_channel`` (``zarr_destriper.py:1214-1267``) wired to the GPU chunk map.
+
+    For every ``<channel>/<tile>.zarr``: pick the retrospective flat of the laser side the tile belongs to
+    (``laser_tiles`` = ``{side: [tile stems]}``, ``ValueError`` for a tile in neither, ``:1239-1247``), build the
+    ``shadow_correction`` dict (:func:`load_shadow_correction`), destripe level ``multiscale`` into
+    ``<results>/destriped_data/<channel>/<tile>.zarr/0`` and, on rank 0, write pyramid levels ``1 .. n_levels - 1``
+    (``compute_multiscale``, ``:1176-1192``).  ``parameters`` holds ``cells_config`` / ``no_cells_config``
+    (``:972-973``).  Returns ``{tile name: planes processed by this rank}``.
+    """
+    from . import pyramid
+
+    logger = logger or logging.getLogger("dsx.zarr")
+    channel_dataset = Path(zarr_dataset_path).joinpath(channel_name)
+    destriped_data_folder = Path(results_folder).joinpath("destriped_data")
+    os.makedirs(destriped_data_folder, exist_ok=True)
+    done = {}
+    for tile_path in sorted(channel_dataset.glob("*.zarr")):
+        output_folder = destriped_data_folder.joinpath(f"{channel_name}/{tile_path.name}")
+        flatfield_path = None
+        for side, tiles in laser_tiles.items():
+            tile_path_stem = tile_path.stem.rsplit(".", 1)[0]
+            if tile_path_stem in tiles:
+                flatfield_path = estimated_channel_flats[int(side)]
+                break
+        if flatfield_path is None:
+            raise ValueError(f"Tile {tile_path} not found in {laser_tiles}")
+        flatfield = tif.imread(str(flatfield_path))
+        shadow_correction = load_shadow_correction(derivatives_path, output_folder, flatfield, logger)
+        if shadow_correction["darkfield"] is None:
+            shadow_correction = None  # no derivatives folder: the reference would fail inside the filter
+        src = tile_path.joinpath(multiscale) if tile_path.joinpath(multiscale, ".zarray").exists() else tile_path
+        n, _ = destripe_zarr(
+            str(src),
+            str(output_folder.joinpath("0")),
+            parameters["cells_config"],
+            parameters["no_cells_config"],
+            shadow_correction=shadow_correction,
+            prediction_chunksize=prediction_chunksize,
+            output_chunks=output_chunks,
+            rank=rank,
+            world_size=world_size,
+            device=device,
+            compressor=compressor,
+            logger=logger,
+            tile_name=tile_path.name,
+        )
+        done[tile_path.name] = n
+        if rank == 0 and world_size == 1 and n_levels > 1:
+            pyramid.compute_multiscale(str(output_folder.joinpath("0")), str(output_folder), n_levels=n_levels,
+                                       chunks=output_chunks, compressor=compressor, device=rank if device is None else device)  # fmt: skip
+    return done

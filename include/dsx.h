@@ -138,6 +138,13 @@ int dsx_planes_to_bricks_u16(dsx_ctx* ctx, const void* d_planes, void* d_bricks,
  * xarray_multiscale.reducers.windowed_mean + preserve_dtype.  Asynchronous on the context stream. */
 int dsx_downsample2_u16(dsx_ctx* ctx, const void* d_src, void* d_dst, int Z, int Y, int X);
 
+/* flatfield_correction() of one plane as a stand-alone call (filtering.py:338-414): dark subtraction
+ * (integer planes truncate, :400-403), division by the flat, baseline, clip, uint16.  dark is
+ * [dark_h][dark_w] >= the plane and is cropped to it (:377).  Device pointers, asynchronous.   */
+int dsx_flatfield_correction(dsx_ctx* ctx, const void* d_img, int in_dtype, int H, int W,
+                             const float* d_flat, const float* d_dark, int dark_h, int dark_w,
+                             float baseline, void* d_out);
+
 /* ---- parity / debug hooks (state of the LAST cohort of the last run) ----------------------- */
 /* Per plane of the last cohort: fore/back means and chosen config (filtering.py:459-462). */
 int dsx_get_stats(dsx_ctx* ctx, int plane, double* fore_mean, double* back_mean,

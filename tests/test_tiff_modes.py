@@ -1,0 +1,390 @@
+"""Rows f2 / f4 of SURVEY section 8: shading plumbing and the TIFF / RAW directory mode.
+
+CPU tests: the TIFF codec against files written by the real ``tifffile`` (``oracle/make_golden_tiff.py``), the
+readers with the reference's own test cases (``code/tests/test_readers.py``, ``test_zarr_destriper.py:25-47``),
+flat discovery, and ``batch_filter`` with the GPU call patched (as the reference patches the filter in
+``test_filtering.py:242-281``).  GPU tests (``-m gpu``): the stand-alone ``flatfield_correction`` against the
+golden vectors and the directory / channel drivers end to end against the CPU oracle.
+"""
+
+import json
+import os
+from pathlib import Path
+from unittest.mock import mock_open, patch
+
+import numpy as np
+import pytest
+
+from aind_smartspim_destripe_amd import destriper, mini_tiff, readers, synth
+from aind_smartspim_destripe_amd import zarr_destriper as zd
+from aind_smartspim_destripe_amd.mini_zarr import MiniZarrArray
+
+TIFF_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiff")
+CASES = {  # file -> (seed, shape, dtype) of oracle/make_golden_tiff.py
+    "u16_le.tif": (1, (37, 53), np.uint16),
+    "u16_be.tif": (2, (37, 53), np.uint16),
+    "u16_deflate.tif": (3, (37, 53), np.uint16),
+    "u16_deflate_pred.tif": (4, (37, 53), np.uint16),
+    "u16_big.tif": (5, (37, 53), np.uint16),
+    "u16_pages.tif": (6, (3, 20, 24), np.uint16),
+    "f32.tif": (7, (37, 53), np.float32),
+    "u16_tiled.tif": (8, (37, 53), np.uint16),
+    "u8_strips.tif": (9, (37, 53), np.uint8),
+}
+
+
+def _plane(seed, shape, dtype):
+    rs = np.random.RandomState(seed)
+    if np.dtype(dtype).kind == "f":
+        return rs.rand(*shape).astype(dtype)
+    return rs.randint(0, np.iinfo(dtype).max + 1, shape).astype(dtype)
+
+
+# ------------------------------------------------------------------------------------------ TIFF
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_mini_tiff_reads_tifffile_output(name, tmp_path):
+    seed, shape, dtype = CASES[name]
+    want = _plane(seed, shape, dtype)
+    got = mini_tiff.imread(os.path.join(TIFF_DIR, name))
+    assert got.dtype == want.dtype and got.dtype.isnative
+    np.testing.assert_array_equal(got, want)
+    for comp in (None, 1):  # and our own writer round-trips
+        mini_tiff.imwrite(str(tmp_path / "rt.tiff"), want, compression=comp)
+        back = mini_tiff.imread(str(tmp_path / "rt.tiff"))
+        assert back.dtype == want.dtype
+        np.testing.assert_array_equal(back, want)
+
+
+def test_mini_tiff_errors(tmp_path):
+    p = tmp_path / "bad.tif"
+    p.write_bytes(b"not a tiff at all")
+    with pytest.raises(mini_tiff.TiffError):
+        mini_tiff.imread(str(p))
+    with pytest.raises(FileNotFoundError):
+        mini_tiff.imread(str(tmp_path / "missing.tif"))
+    with pytest.raises(ValueError):
+        mini_tiff.imwrite(str(p), np.zeros((2, 2, 2, 2), np.uint16))
+    with pytest.raises(ValueError):
+        mini_tiff.imwrite(str(p), np.zeros((2, 2), np.complex64))
+    # a truncated file must not read out of bounds
+    raw = open(os.path.join(TIFF_DIR, "u16_le.tif"), "rb").read()
+    p.write_bytes(raw[:2000] + raw[-300:])
+    with pytest.raises(Exception):
+        mini_tiff.imread(str(p))
+
+
+def test_written_tiff_is_readable_by_tifffile(tmp_path):
+    """Cross-check with the real library when the reference interpreter is around (this container)."""
+    import subprocess
+
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py):
+        pytest.skip("no interpreter with tifffile")
+    a = _plane(21, (64, 48), np.uint16)
+    mini_tiff.imwrite(str(tmp_path / "a.tiff"), a)
+    mini_tiff.imwrite(str(tmp_path / "s.tiff"), np.stack([a, a + 1]), compression=6)
+    np.save(str(tmp_path / "a.npy"), a)
+    code = (
+        "import sys, numpy as np, tifffile; d = sys.argv[1]; a = np.load(d + '/a.npy');"
+        "assert np.array_equal(tifffile.imread(d + '/a.tiff'), a);"
+        "s = tifffile.imread(d + '/s.tiff'); assert s.shape == (2, 64, 48) and np.array_equal(s[1], a + 1)"
+    )
+    r = subprocess.run([py, "-c", code, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    if "No module named" in r.stderr:
+        pytest.skip("tifffile not importable there")
+    assert r.returncode == 0, r.stderr
+
+
+# --------------------------------------------------------------------------------------- readers
+
+
+def test_get_extension():  # code/tests/test_readers.py:22-30
+    assert readers._get_extension("image.tif") == ".tif"
+    assert readers._get_extension("/path/to/image.png") == ".png"
+    assert readers._get_extension("C:\\Images\\image.raw") == ".raw"
+    assert readers._get_extension("no_extension") == ""
+
+
+def test_raw_imread_endianness_mocked():  # code/tests/test_readers.py:32-66
+    with patch("numpy.memmap") as mm:
+        mm.side_effect = [np.array([300, 200], dtype=">u4"), np.array([100, 50], dtype="<u4"),
+                          np.ones((300, 200), dtype=">u2")]  # fmt: skip
+        r = readers.raw_imread("fake_path.raw")
+        assert r.shape == (300, 200) and r.dtype == np.dtype(">u2")
+    with patch("numpy.memmap") as mm:
+        mm.side_effect = [np.array([100, 50], dtype=">u4"), np.array([300, 200], dtype="<u4"),
+                          np.ones((300, 200), dtype="<u2")]  # fmt: skip
+        r = readers.raw_imread("fake_path.raw")
+        assert r.shape == (300, 200) and r.dtype == np.dtype("<u2")
+    with patch("numpy.memmap", side_effect=OSError("File not found")):
+        with pytest.raises(OSError):
+            readers.raw_imread("invalid_path.raw")
+
+
+def test_imread_dispatch_and_real_files(tmp_path):
+    with patch("aind_smartspim_destripe_amd.readers.raw_imread", return_value=np.zeros((10, 10))), patch(
+        "aind_smartspim_destripe_amd.mini_tiff.imread", return_value=np.ones((10, 10))
+    ):  # code/tests/test_readers.py:68-80
+        assert np.array_equal(readers.imread("image.raw"), np.zeros((10, 10)))
+        assert np.array_equal(readers.imread("image.tif"), np.ones((10, 10)))
+        assert np.array_equal(readers.imread(Path("image.tiff")), np.ones((10, 10)))
+    assert readers.imread("image.jpg") is None
+    with pytest.raises(NotImplementedError):
+        readers.imread("image.png")
+    # a real little-endian and a real big-endian .raw plane
+    a = _plane(3, (40, 40), np.uint16)
+    for order in ("<", ">"):
+        p = tmp_path / "p{}.raw".format("le" if order == "<" else "be")
+        with open(p, "wb") as f:
+            f.write(np.array([40, 40], dtype=order + "u4").tobytes())
+            f.write(a.astype(order + "u2").tobytes())
+        np.testing.assert_array_equal(np.asarray(readers.imread(str(p))), a)
+
+
+# ------------------------------------------------------------------------------ shading plumbing
+
+
+def test_read_json_as_dict():  # code/tests/test_zarr_destriper.py:25-47
+    with patch("builtins.open", mock_open(read_data='{"key": "value"}')), patch("os.path.exists", return_value=True):
+        assert zd.read_json_as_dict("fake_path.json") == {"key": "value"}
+    with patch("builtins.open", side_effect=UnicodeDecodeError("utf-8", b"", 0, 1, "error")), patch(
+        "os.path.exists", return_value=True
+    ):
+        with pytest.raises(UnicodeDecodeError):
+            zd.read_json_as_dict("fake_path.json")
+    with patch("os.path.exists", return_value=False):
+        assert zd.read_json_as_dict("fake_path.json") == {}
+
+
+def _derivatives(tmp_path, n_flats=2, tile_config=True, side_missing=False):
+    d = tmp_path / "derivatives"
+    d.mkdir()
+    cfg = {
+        "t0": {"Laser": "488", "X": "431040", "Y": "368180", "Side": "0"},
+        "t1": {"Laser": "488", "X": "431040", "Y": "394100", "Side": "1"},
+        "t2": {"Laser": "561", "X": "431040", "Y": "368180", "Side": "1"},
+        "t3": {"Laser": "488", "X": "465600", "Y": "368180", "Side": "1"},
+    }
+    if side_missing:
+        del cfg["t1"]["Side"]
+    meta = {"tile_config": cfg} if tile_config else {"other": 1}
+    (d / "metadata.json").write_text(json.dumps(meta))
+    flats = []
+    for i, name in enumerate(["FlatReal488_10.tif", "FlatReal488_9.tif", "FlatReal488_11.tif"][:n_flats]):
+        f = (1000 + 100 * i + np.arange(24 * 32).reshape(24, 32)).astype(np.uint16)
+        mini_tiff.imwrite(str(d / name), f)
+        flats.append((name, f))
+    mini_tiff.imwrite(str(d / "FlatReal561_0.tif"), np.zeros((24, 32), np.uint16))
+    mini_tiff.imwrite(str(d / "DarkMaster_cropped.tif"), np.full((30, 40), 100, np.uint16))
+    return d, dict(flats)
+
+
+def test_get_microscope_flats(tmp_path):
+    d, flats = _derivatives(tmp_path)
+    got, cfg = zd.get_microscope_flats("Ex_488_Em_525", d)
+    assert cfg == {"431040": {"368180": 0, "394100": 1}, "465600": {"368180": 1}}
+    # natural order: FlatReal488_9 before FlatReal488_10
+    np.testing.assert_array_equal(got[0], flats["FlatReal488_9.tif"])
+    np.testing.assert_array_equal(got[1], flats["FlatReal488_10.tif"])
+    assert zd.get_microscope_flats("NoWavelength", d) == (None, None)
+    assert zd.get_microscope_flats("Ex_488_Em_525", tmp_path / "nowhere") == (None, None)
+
+
+def test_get_microscope_flats_errors(tmp_path):
+    (tmp_path / "a").mkdir(), (tmp_path / "b").mkdir(), (tmp_path / "c").mkdir()
+    d, _ = _derivatives(tmp_path / "a", n_flats=3)
+    with pytest.raises(ValueError):
+        zd.get_microscope_flats("Ex_488_Em_525", d)
+    d, _ = _derivatives(tmp_path / "b", tile_config=False)
+    with pytest.raises(ValueError):
+        zd.get_microscope_flats("Ex_488_Em_525", d)
+    d, _ = _derivatives(tmp_path / "c", side_missing=True)
+    with pytest.raises(KeyError):
+        zd.get_microscope_flats("Ex_488_Em_525", d)
+
+
+def test_load_shadow_correction(tmp_path):
+    d, flats = _derivatives(tmp_path)
+    out = tmp_path / "results" / "Ex_488_Em_525" / "431040_368180.zarr"
+    sc = zd.load_shadow_correction(d, out)  # microscope flats, normalised into [1, 2] (float16)
+    assert sc["retrospective"] is False and sc["tile_config"]["431040"]["394100"] == 1
+    assert sc["flatfield"].shape == (2, 24, 32) and sc["flatfield"].dtype == np.float16
+    assert float(sc["flatfield"].min()) == 1.0 and float(sc["flatfield"].max()) == 2.0
+    assert sc["darkfield"].shape == (30, 40) and int(sc["darkfield"][0, 0]) == 100
+    retro = np.ones((24, 32), np.float32)
+    sc = zd.load_shadow_correction(d, out, flatfield=retro)
+    assert sc["retrospective"] is True and sc["flatfield"] is retro and sc["tile_config"] is None
+    os.remove(d / "DarkMaster_cropped.tif")
+    with pytest.raises(FileNotFoundError):
+        zd.load_shadow_correction(d, out, flatfield=retro)
+    sc = zd.load_shadow_correction(tmp_path / "nowhere", out, flatfield=retro)
+    assert sc["darkfield"] is None and sc["retrospective"] is True
+
+
+# --------------------------------------------------------------------------------- directory mode
+
+
+def test_imsave_naming_and_errors(tmp_path):
+    a = _plane(5, (16, 20), np.uint16)
+    destriper.imsave(str(tmp_path / "a.tif"), a)
+    destriper.imsave(str(tmp_path / "b.raw"), a)
+    destriper.imsave(str(tmp_path / "c.raw"), a, output_format=".tif")
+    assert sorted(os.listdir(tmp_path)) == ["a.tiff", "b.tiff", "c.tif"]
+    np.testing.assert_array_equal(mini_tiff.imread(str(tmp_path / "b.tiff")), a)
+    with pytest.raises(NotImplementedError):
+        destriper.imsave(str(tmp_path / "d.jpg"), a)
+    with pytest.raises(ValueError):
+        destriper.imsave(str(tmp_path / "d.tif"), a, output_format=".jpg")
+
+
+def _image_tree(root, n=5, shape=(64, 96)):
+    (root / "X_0" / "X_0_Y_0").mkdir(parents=True)
+    (root / "X_0" / "X_0_Y_1").mkdir(parents=True)
+    planes = {}
+    for k in range(n):
+        sub = "X_0_Y_0" if k % 2 == 0 else "X_0_Y_1"
+        p = root / "X_0" / sub / "{:06d}.tif".format(k)
+        a = synth.synthetic_plane(k, *shape)
+        mini_tiff.imwrite(str(p), a)
+        planes[p.relative_to(root)] = a
+    (root / "X_0" / "X_0_Y_0" / "broken.tif").write_bytes(b"II*\0garbage")
+    (root / "notes.txt").write_text("acquisition notes")
+    (root / "ASI.ini").write_text("[stage]")
+    (root / "ignored.dat").write_text("x")
+    return planes
+
+
+def test_find_all_images_and_batch_filter_patched(tmp_path):
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir(), dst.mkdir()
+    planes = _image_tree(src)
+    found = destriper._find_all_images(src, src, dst)
+    assert len(found) == 6 and (dst / "X_0" / "X_0_Y_1").is_dir()
+    calls = []
+
+    def fake(stack, **kw):
+        calls.append((stack.shape, kw["input_tile_path"], kw["out_dtype"], kw.get("microscope_high_int", 2700)))
+        return (stack // 2).astype(kw["out_dtype"])
+
+    with patch("aind_smartspim_destripe_amd.filtering.destripe_planes", side_effect=fake):
+        n = destriper.batch_filter(src, dst, workers=2, chunks=4, high_int_filt_params=synth.CELLS_CONFIG,
+                                   low_int_filt_params=synth.NO_CELLS_CONFIG, shadow_correction=None)  # fmt: skip
+    assert n == 5 and sum(c[0][0] for c in calls) == 5
+    assert all(c[2] == np.uint16 and c[3] == 2700 for c in calls)  # uint16 sources, default high_int of the TIFF path
+    for rel, a in planes.items():
+        got = mini_tiff.imread(str((dst / rel).with_suffix(".tiff")))
+        assert got.dtype == np.uint16
+        np.testing.assert_array_equal(got, a // 2)
+    log = (dst / "destripe_log.txt").read_text()
+    assert "broken.tif" in log and log.startswith("Error reading the following images")
+    assert (dst / "notes.txt").read_text() == "acquisition notes" and (dst / "ASI.ini").exists()
+    assert not (dst / "ignored.dat").exists()
+
+
+# --------------------------------------------------------------------------------------------- GPU
+
+
+@pytest.mark.gpu
+def test_gpu_flatfield_correction_golden(golden_misc):
+    from aind_smartspim_destripe_amd import filtering
+
+    g = golden_misc
+    out = filtering.flatfield_correction(
+        np.array([[[10, 20], [30, 40]]]), np.array([[[2, 2], [2, 2]]]), np.array([[[1, 1], [1, 1]]])
+    )  # code/tests/test_filtering.py:226-240
+    assert out.dtype == np.uint16
+    np.testing.assert_array_equal(out, g["flat_kat"])
+    with pytest.raises(ValueError):
+        filtering.flatfield_correction(
+            np.array([[[10, 20], [30, 40]]]), np.array([[[2, 2], [2, 2]]]), np.array([[[1, 1]]])
+        )
+    with pytest.raises(ValueError):
+        filtering.flatfield_correction(np.zeros((4, 4)), np.ones((3, 4)), np.zeros((4, 4)))
+    out = filtering.flatfield_correction(g["flat_f__img"], g["flat_f__flat"], g["flat_f__dark"])
+    d = np.abs(out.astype(np.int64) - g["flat_f__out"].astype(np.int64))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3  # float32 division next to a truncation boundary
+    # integer planes truncate after the dark subtraction (filtering.py:400-403)
+    img = np.array([[1000, 50], [300, 65535]], dtype=np.uint16)
+    dark = np.array([[100.5, 60.0], [0.25, 0.0]])
+    flat = np.array([[1.0, 1.0], [0.5, 0.5]])
+    np.testing.assert_array_equal(filtering.flatfield_correction(img, flat, dark), [[899, 0], [598, 65535]])
+
+
+@pytest.mark.gpu
+def test_gpu_batch_filter_and_read_filter_save(tmp_path):
+    from oracle import destripe_oracle as orc
+
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir(), dst.mkdir()
+    planes = _image_tree(src, n=5, shape=(96, 128))
+    n = destriper.batch_filter(src, dst, workers=4, chunks=3, high_int_filt_params=synth.CELLS_CONFIG,
+                               low_int_filt_params=synth.NO_CELLS_CONFIG, shadow_correction=None)  # fmt: skip
+    assert n == 5
+
+    def check(path, a):
+        got = mini_tiff.imread(str(path))
+        ref = orc.filter_stripes(a, "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None)  # default 2700
+        d = np.abs(got.astype(np.int64) - ref.astype(np.uint16).astype(np.int64))
+        assert got.dtype == np.uint16 and d.max() <= 1 and (d > 0).mean() < 2e-3
+
+    for rel, a in planes.items():
+        check((dst / rel).with_suffix(".tiff"), a)
+    rel, a = next(iter(planes.items()))
+    destriper.read_filter_save(str(dst), str(src / rel), str(dst / "single.tif"), synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG)
+    check(dst / "single.tiff", a)
+    # an unreadable file is logged and skipped
+    destriper.read_filter_save(str(dst), str(src / "X_0" / "X_0_Y_0" / "broken.tif"), str(dst / "b.tif"),
+                               synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG)  # fmt: skip
+    assert not (dst / "b.tiff").exists()
+
+
+@pytest.mark.gpu
+def test_gpu_destripe_channel_with_shading_and_pyramid(tmp_path):
+    """Two tiles of one channel, retrospective flat per laser side, microscope dark, pyramid levels."""
+    from oracle import destripe_oracle as orc
+    from oracle import format_oracle as fo
+
+    H, W, Z = 64, 96, 12
+    chan = tmp_path / "data" / "Ex_488_Em_525"
+    tiles = {"431040_368180": 0, "431040_394100": 1}
+    stacks = {}
+    for t, (name, side) in enumerate(tiles.items()):
+        stack = synth.synthetic_stack(Z, H, W, n_unique=4) + np.uint16(t)
+        a = MiniZarrArray.create(str(chan / (name + ".zarr") / "0"), (1, 1, Z, H, W), (1, 1, 4, 32, 32), np.uint16,
+                                 compressor="zlib")  # fmt: skip
+        a[0, 0] = stack
+        stacks[name] = stack
+    d = tmp_path / "derivatives"
+    d.mkdir()
+    mini_tiff.imwrite(str(d / "DarkMaster_cropped.tif"), np.full((H + 8, W + 8), 90, np.uint16))
+    yy, xx = np.mgrid[0:H, 0:W]
+    flats = []
+    for side in (0, 1):
+        f = (1.0 + 0.2 * side - 0.3 * ((yy - H / 2) / H) ** 2 - 0.2 * ((xx - W / 2) / W) ** 2).astype(np.float32)
+        mini_tiff.imwrite(str(d / "flat_{}.tif".format(side)), f)
+        flats.append(f)
+    params = {"cells_config": synth.CELLS_CONFIG, "no_cells_config": synth.NO_CELLS_CONFIG}
+    with pytest.raises(ValueError):
+        zd.destripe_channel(tmp_path / "data", d, "Ex_488_Em_525", tmp_path / "results",
+                            [d / "flat_0.tif", d / "flat_1.tif"], {"0": ["431040_368180"]}, params,
+                            prediction_chunksize=(4, H, W))  # fmt: skip
+    done = zd.destripe_channel(tmp_path / "data", d, "Ex_488_Em_525", tmp_path / "results2",
+                               [d / "flat_0.tif", d / "flat_1.tif"],
+                               {"0": ["431040_368180"], "1": ["431040_394100"]}, params,
+                               prediction_chunksize=(4, H, W), output_chunks=(1, 1, 4, 32, 32),
+                               compressor="zlib")  # fmt: skip
+    assert done == {"431040_368180.zarr": Z, "431040_394100.zarr": Z}
+    dark = np.full((H + 8, W + 8), 90, np.uint16)
+    for name, side in tiles.items():
+        out_dir = tmp_path / "results2" / "destriped_data" / "Ex_488_Em_525" / (name + ".zarr")
+        got = MiniZarrArray.open(str(out_dir / "0"))[0, 0]
+        sc = {"retrospective": True, "flatfield": flats[side], "darkfield": dark, "tile_config": None}
+        for z in range(Z):
+            ref = orc.filter_stripes(stacks[name][z], name, synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, sc, 2500)
+            dd = np.abs(got[z].astype(np.int64) - ref.astype(np.int64))
+            assert dd.max() <= 1 and (dd > 0).mean() < 2e-3, (name, z, int(dd.max()))
+        pyr = fo.pyramid(got, 3)
+        for lvl in (1, 2):
+            np.testing.assert_array_equal(MiniZarrArray.open(str(out_dir / str(lvl)))[0, 0], pyr[lvl])
