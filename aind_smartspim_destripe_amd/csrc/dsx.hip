@@ -840,6 +840,38 @@ int dsx_flatfield_correction(dsx_ctx* ctx, const void* d_img, int in_dtype, int 
   return DSX_OK;
 }
 
+int dsx_foreground_background(dsx_ctx* ctx, const void* d_img, int in_dtype, size_t n, float cutoff,
+                              double* fore_mean, double* back_mean, void* d_mask) {
+  if (!ctx || !d_img || !fore_mean || !back_mean) return DSX_EINVAL;
+  if (in_dtype != DSX_U16 && in_dtype != DSX_F32) return fail(ctx, DSX_EINVAL, "unknown element type");
+  if (n == 0) return fail(ctx, DSX_EINVAL, "empty image");
+  DSX_HIP(hipSetDevice(ctx->device));
+  char* d_acc = nullptr;
+  DSX_HIP(hipMalloc(&d_acc, 32));
+  int rc = DSX_OK;
+  do {
+    if (hipMemsetAsync(d_acc, 0, 32, ctx->stream) != hipSuccess) { rc = DSX_EHIP; break; }
+    dsx::FgBgArgs a;
+    a.src = d_img; a.mask = (uint8_t*)d_mask; a.acc = (double*)d_acc; a.cnt = (unsigned long long*)(d_acc + 16);
+    a.n = n; a.cutoff = cutoff;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    if (in_dtype == DSX_U16) hipLaunchKernelGGL(dsx::k_fgbg<true>, dim3(blocks), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(dsx::k_fgbg<false>, dim3(blocks), dim3(256), 0, ctx->stream, a);
+    char h[32];
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(h, d_acc, 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = DSX_EHIP; break; }
+    const double* acc = (const double*)h;
+    const unsigned long long* cnt = (const unsigned long long*)(h + 16);
+    // an empty class has mean 0.0 (filtering.py:84-85)
+    *fore_mean = cnt[0] ? acc[0] / (double)cnt[0] : 0.0;
+    *back_mean = cnt[1] ? acc[1] / (double)cnt[1] : 0.0;
+  } while (0);
+  (void)hipFree(d_acc);
+  if (rc != DSX_OK) return fail(ctx, rc, "foreground / background statistic failed");
+  return DSX_OK;
+}
+
 /* ---- debug hooks ---------------------------------------------------------------------------- */
 int dsx_set_stop_after(dsx_ctx* ctx, int stage) {
   if (!ctx || stage < 0 || stage > 2) return DSX_EINVAL;

@@ -11,6 +11,7 @@
 // All three are pure HBM streaming: one workgroup per row segment, 16-byte accesses, no LDS.  Row / slab
 // indices come from blockIdx (scalar registers), so the only per-lane integer division is x / cx.
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -142,6 +143,49 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
   float c = t / a.flat[i] - a.baseline;
   c = fminf(fmaxf(c, 0.f), 65535.f);
   a.dst[i] = (uint16_t)c;
+}
+
+// ---- a2 as a stand-alone call: get_foreground_background_mean() (filtering.py:54-88) ------------------
+// mask = sigmoid(float16((float16(x) - 400) / 20)) > threshold.  Everything after float16(x) is monotone,
+// so the host turns the threshold into the smallest float16 pixel value that passes (`cutoff`) and the
+// kernel compares float16(x) >= cutoff (round-to-nearest-even conversion, as NumPy's astype).
+// acc[0..1] = sum of foreground / background pixels (double), cnt[0..1] = their counts.
+struct FgBgArgs {
+  const void* src;
+  uint8_t* mask;  // nullable
+  double* acc;
+  unsigned long long* cnt;
+  size_t n;
+  float cutoff;
+};
+
+template <bool U16>
+__global__ __launch_bounds__(256) void k_fgbg(FgBgArgs a) {
+  double s[2] = {0.0, 0.0};
+  unsigned long long c[2] = {0, 0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+    const float v = U16 ? (float)reinterpret_cast<const uint16_t*>(a.src)[i] : reinterpret_cast<const float*>(a.src)[i];
+    const bool fg = __half2float(__float2half_rn(v)) >= a.cutoff;
+    if (a.mask) a.mask[i] = fg ? 1 : 0;
+    s[fg ? 0 : 1] += (double)v;
+    c[fg ? 0 : 1] += 1;
+  }
+  __shared__ double ss[2][4];
+  __shared__ unsigned long long sc[2][4];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    for (int o = 32; o > 0; o >>= 1) {
+      s[k] += __shfl_down(s[k], o);
+      c[k] += __shfl_down(c[k], o);
+    }
+    if ((threadIdx.x & 63) == 0) { ss[k][threadIdx.x >> 6] = s[k]; sc[k][threadIdx.x >> 6] = c[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int k = threadIdx.x;
+    atomicAdd(&a.acc[k], ss[k][0] + ss[k][1] + ss[k][2] + ss[k][3]);
+    atomicAdd(&a.cnt[k], sc[k][0] + sc[k][1] + sc[k][2] + sc[k][3]);
+  }
 }
 
 }  // namespace dsx

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "dsx_timer_start", "dsx_timer_stop", "dsx_profile_enable", "dsx_profile_read",
     "dsx_get_stats", "dsx_get_thresholds", "dsx_get_level", "dsx_set_stop_after",
     "dsx_bricks_to_planes_u16", "dsx_planes_to_bricks_u16", "dsx_downsample2_u16",
-    "dsx_flatfield_correction",
+    "dsx_flatfield_correction", "dsx_foreground_background",
 ]  # fmt: skip
 
 
@@ -114,6 +114,8 @@ def load_library(path=None):
     lib.dsx_bricks_to_planes_u16.argtypes = [vp, vp, vp] + [i32] * 7
     lib.dsx_planes_to_bricks_u16.argtypes = [vp, vp, vp] + [i32] * 7
     lib.dsx_downsample2_u16.argtypes = [vp, vp, vp, i32, i32, i32]
+    lib.dsx_foreground_background.argtypes = [vp, vp, i32, ctypes.c_size_t, ctypes.c_float,
+                                              ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), vp]  # fmt: skip
     lib.dsx_flatfield_correction.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, ctypes.c_float, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
@@ -336,6 +338,27 @@ class DestripeEngine:
         if rc == -1:
             raise ValueError(self._lib.dsx_last_error(self._ctx).decode())
         self._check(rc)
+
+    def foreground_background(self, image, cutoff, want_mask=True):
+        """``(fore_mean, back_mean, mask uint8)`` of a host image (uint16 / float32, any shape)."""
+        a = np.ascontiguousarray(image)
+        d_img = self.alloc(max(a.nbytes, 16))
+        d_mask = self.alloc(max(a.size, 16)) if want_mask else None
+        try:
+            d_img.upload(a)
+            f, b = ctypes.c_double(), ctypes.c_double()
+            rc = self._lib.dsx_foreground_background(self._ctx, ctypes.c_void_p(d_img.ptr), _dtype_code(a.dtype), a.size,
+                                                     float(cutoff), ctypes.byref(f), ctypes.byref(b),
+                                                     ctypes.c_void_p(d_mask.ptr) if want_mask else None)  # fmt: skip
+            if rc == -1:
+                raise ValueError(self._lib.dsx_last_error(self._ctx).decode())
+            self._check(rc)
+            mask = d_mask.download(a.shape, np.uint8) if want_mask else None
+            return f.value, b.value, mask
+        finally:
+            d_img.free()
+            if d_mask is not None:
+                d_mask.free()
 
     def flatfield_correction(self, plane, flatfield, darkfield, baseline=0.0):
         """One host plane (uint16 / float32) through ``dsx_flatfield_correction``; uint16 result."""

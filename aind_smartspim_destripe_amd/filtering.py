@@ -10,9 +10,11 @@ Same names, argument meaning and error behaviour as the reference
   function; it forwards to :func:`log_space_fft_filtering`).
 * :func:`destripe_planes` is the batched form the Zarr chunk map uses instead of the per-plane
   z-loop of ``execute_worker`` (``zarr_destriper.py:319-327``).
-* The small host-side helpers of the reference module (``sigmoid``, ``notch``, ``gaussian_filter``,
-  ``get_hemisphere_flatfield``, ...) are plain NumPy here as they are there; they are not on the
-  hot path (the engine builds its own gain tables and evaluates the statistic on the device).
+* :func:`get_foreground_background_mean` (``:54-88``) and :func:`flatfield_correction` (``:338-414``) called
+  on their own also run on the device (``dsx_foreground_background``, ``dsx_flatfield_correction``).
+* The remaining helpers (``sigmoid``, ``notch``, ``gaussian_filter``, ``normalize_image``,
+  ``get_hemisphere_flatfield``) are parameter / lookup helpers, plain NumPy here as they are there; the
+  filter never calls them (the engine builds its own gain tables).
 """
 
 import math
@@ -40,21 +42,42 @@ def foreground_fraction(img: np.array, center: float, crossover: float) -> float
     return sigmoid(z)
 
 
-def get_foreground_background_mean(img: np.array, threshold_mask: Optional[float] = 0.3) -> Tuple:
-    """``filtering.py:54-88``: (foreground mean, background mean, float16 mask image).
+def _foreground_cutoff(threshold_mask):
+    """Smallest float16 pixel value v with ``sigmoid((v - 400) / 20) > threshold_mask`` in the reference's
+    float16 arithmetic (``filtering.py:75-78``), found by evaluating every finite float16 value; ``inf`` when
+    no pixel value passes.  The decision is monotone in v, so ``float16(pixel) >= cutoff`` is the mask."""
+    v = np.arange(0x0000, 0x7C00, dtype=np.uint16).view(np.float16)  # non-negative finite values, ascending
+    v = np.concatenate([-v[:0:-1], v])  # negative ones (descending bit pattern = ascending value) first
+    with np.errstate(over="ignore"):
+        ok = foreground_fraction(v, 400, 20) > threshold_mask
+    if not ok.any():
+        return float("inf")
+    if ok.all():
+        return -float("inf")
+    first = int(np.argmax(ok))
+    if not ok[first:].all():  # not monotone for this threshold (cannot happen for a sigmoid)
+        raise ValueError("threshold_mask does not define a cutoff")
+    return float(v[first])
 
-    Host helper kept for API parity; ``filter_stripes`` evaluates the same statistic on the GPU.
+
+def get_foreground_background_mean(img: np.array, threshold_mask: Optional[float] = 0.3, device: int = 0) -> Tuple:
+    """``filtering.py:54-88`` on the GPU (``dsx_foreground_background``): (foreground mean, background mean,
+    float16 mask image).  ``filter_stripes`` evaluates the same statistic fused into its first kernel.
     """
     img = np.asarray(img)
-    with np.errstate(over="ignore"):
-        cell_for = foreground_fraction(img.astype(np.float16), 400, 20)
-    cell_for[cell_for > threshold_mask] = 1
-    cell_for[cell_for <= threshold_mask] = 0
-    foreground = img[cell_for == 1]
-    background = img[cell_for == 0]
-    foreground_mean = foreground.mean() if foreground.size else 0.0
-    background_mean = background.mean() if background.size else 0.0
-    return foreground_mean, background_mean, cell_for
+    if img.size == 0:
+        return 0.0, 0.0, np.zeros(img.shape, np.float16)
+    cutoff = _foreground_cutoff(threshold_mask)
+    eng = next((e[0] for k, e in _ENGINES.items() if k[0] == device), None)
+    own = eng is None
+    if own:
+        eng = _engine.DestripeEngine(device)
+    try:
+        fore, back, mask = eng.foreground_background(_as_plane_dtype(img), cutoff)
+    finally:
+        if own:
+            eng.close()
+    return fore, back, mask.astype(np.float16)
 
 
 def notch(n, sigma):

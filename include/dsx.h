@@ -145,6 +145,13 @@ int dsx_flatfield_correction(dsx_ctx* ctx, const void* d_img, int in_dtype, int 
                              const float* d_flat, const float* d_dark, int dark_h, int dark_w,
                              float baseline, void* d_out);
 
+/* get_foreground_background_mean() as a stand-alone call (filtering.py:54-88): a pixel is foreground
+ * when float16(pixel) >= cutoff (the host derives cutoff from threshold_mask, 383.25 for the default
+ * 0.3); means in double, 0.0 for an empty class; d_mask (nullable) gets 1 / 0 per pixel.
+ * Synchronous.  Inside dsx_run_* the same statistic is fused into the first analysis kernel.      */
+int dsx_foreground_background(dsx_ctx* ctx, const void* d_img, int in_dtype, size_t n, float cutoff,
+                              double* fore_mean, double* back_mean, void* d_mask);
+
 /* ---- parity / debug hooks (state of the LAST cohort of the last run) ----------------------- */
 /* Per plane of the last cohort: fore/back means and chosen config (filtering.py:459-462). */
 int dsx_get_stats(dsx_ctx* ctx, int plane, double* fore_mean, double* back_mean,

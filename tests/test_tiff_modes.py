@@ -388,3 +388,36 @@ def test_gpu_destripe_channel_with_shading_and_pyramid(tmp_path):
         pyr = fo.pyramid(got, 3)
         for lvl in (1, 2):
             np.testing.assert_array_equal(MiniZarrArray.open(str(out_dir / str(lvl)))[0, 0], pyr[lvl])
+
+
+@pytest.mark.gpu
+def test_gpu_foreground_background_mean_golden(golden_misc):
+    """Stand-alone a2 (``filtering.py:54-88``) on the device against vectors from the real reference."""
+    from aind_smartspim_destripe_amd import filtering
+
+    g = golden_misc
+    allv = np.arange(65536, dtype=np.uint16)
+    for dt, x in (("u16", allv), ("f32", allv.astype(np.float32))):
+        fore, back, mask = filtering.get_foreground_background_mean(x)
+        np.testing.assert_allclose([fore, back], g["fgbg_all__{}__means".format(dt)], rtol=1e-6)
+        assert mask.dtype == np.float16 and mask.shape == x.shape
+        np.testing.assert_array_equal(mask.astype(np.uint8), np.unpackbits(g["fgbg_all__{}__mask".format(dt)])[:65536])
+    fr = g["fgbg_frac__in"]  # fractional float32 pixels around the cut-off
+    fore, back, mask = filtering.get_foreground_background_mean(fr)
+    np.testing.assert_array_equal(mask.astype(np.uint8), g["fgbg_frac__mask"])
+    np.testing.assert_allclose([fore, back], g["fgbg_frac__means"], rtol=1e-6)
+    # the host-side cutoff reproduces the decision for every float16 bit pattern at the default threshold
+    h = np.arange(65536, dtype=np.uint16).view(np.float16)
+    table = np.unpackbits(g["f16_mask_table"])[:65536].astype(bool)
+    ok = np.isfinite(h)
+    np.testing.assert_array_equal((h >= np.float16(filtering._foreground_cutoff(0.3)))[ok], table[ok])
+    # empty / all-background / all-foreground (code/tests/test_filtering.py:68-114)
+    f, b, m = filtering.get_foreground_background_mean(np.array([]))
+    assert f == 0.0 and b == 0.0 and m.size == 0
+    f, b, m = filtering.get_foreground_background_mean(np.array([10, 20, 30, 40, 50]), 1.0)
+    assert f == 0.0 and b == 30.0 and not m.any()
+    f, b, m = filtering.get_foreground_background_mean(np.array([400, 420, 430, 440, 460]), 0.0)
+    assert f == 430.0 and b == 0.0 and m.all()
+    img = np.array([[100, 200], [500, 700]], dtype=np.uint16)
+    f, b, m = filtering.get_foreground_background_mean(img)
+    assert (f, b) == (600.0, 150.0) and m.tolist() == [[0.0, 0.0], [1.0, 1.0]]
