@@ -78,30 +78,61 @@ def broadcast_constants(dist, engine, rank):
     return nbytes
 
 
-def cpu_baseline(n_planes):
-    """The NumPy oracle (a port of the reference algorithm) on one host core, bounded sample."""
+def cpu_worker(first, count, start_at):
+    """Child process of the CPU baseline: the NumPy oracle over `count` planes on one thread.  Prints
+    "start end" (epoch seconds of its timed region).  Never touches the GPU."""
     from oracle import destripe_oracle as orc
 
-    planes = synth.synthetic_bank(n_planes, H, W)
-    orc.filter_stripes(planes[0][:256, :256].copy(), "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
-                       synth.ZARR_PATH_HIGH_INT)  # fmt: skip  (warm numpy)
-    t0 = time.perf_counter()
-    for k in range(n_planes):
-        out = orc.filter_stripes(planes[k], "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
-                                 synth.ZARR_PATH_HIGH_INT)  # fmt: skip
+    p = synth.synthetic_plane(0, 256, 256)
+    orc.filter_stripes(p, "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT)  # warm numpy
+    planes = [synth.synthetic_plane(k % 32, H, W) for k in range(first, first + count)]
+    while time.time() < start_at:  # common start so that the workers really run side by side
+        time.sleep(0.01)
+    t0 = time.time()
+    for p in planes:
+        out = orc.filter_stripes(p, "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT)
         np.clip(out, 0, 65535).astype(np.uint16)
-    dt = time.perf_counter() - t0
+    print("{:.6f} {:.6f}".format(t0, time.time()), flush=True)
+
+
+def cpu_baseline(n_planes, procs):
+    """The NumPy oracle (a port of the reference algorithm) on the host cores, bounded sample: `procs`
+    independent single-thread processes (the reference's execution model, zarr_destriper.py:1151-1165),
+    `n_planes` planes in total.  Children are started BEFORE this process initialises the GPU."""
+    import subprocess
+
+    procs = max(1, min(procs, n_planes))
+    per = n_planes // procs
+    start_at = time.time() + 6.0 + 0.6 * per  # imports + warm-up + making the planes
+    kids = [
+        subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i * per), str(per), repr(start_at)],
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        for i in range(procs)
+    ]  # fmt: skip
+    spans = []
+    for k in kids:
+        out, _ = k.communicate(timeout=900)
+        if k.returncode != 0:
+            raise RuntimeError("cpu baseline worker failed")
+        t0, t1 = map(float, out.split()[-2:])
+        spans.append((t0, t1))
+    wall = max(t1 for _, t1 in spans) - min(t0 for t0, _ in spans)
+    busy = sum(t1 - t0 for t0, t1 in spans)
+    done = per * procs
     return {
-        "value": round(n_planes / dt, 4),
+        "value": round(done / wall, 4),
         "unit": "slices/s",
-        "cores": 1,
+        "cores": procs,
         "kind": "port",
-        "sample": "{} synthetic 2048x2048 uint16 planes (bank planes 0..{}), NumPy oracle filter_stripes + uint16 "
-                  "cast, one process, OMP_NUM_THREADS=1, {:.1f} s".format(n_planes, n_planes - 1, dt),
+        "per_core": round(done / busy, 4),
+        "sample": "{} synthetic 2048x2048 uint16 planes ({} per process, {} single-thread processes side by side), "
+                  "NumPy oracle filter_stripes + uint16 cast, {:.1f} s wall".format(done, per, procs, wall),
     }  # fmt: skip
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]))
     # Only the JSON line may reach stdout: library banners (Gloo, RCCL) are written to fd 1 directly,
     # so fd 1 is pointed at stderr for the duration of the run and the line goes to the saved fd.
     sys.stdout.flush()
@@ -114,9 +145,18 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="slices per step per GPU")
     ap.add_argument("--cohort", type=int, default=int(os.environ.get("DSX_COHORT", "256")),
                     help="planes per launch chain (workspace size)")  # fmt: skip
-    ap.add_argument("--cpu-planes", type=int, default=16, help="planes of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-planes", type=int, default=None,
+                    help="planes of the CPU baseline sample (default: 4 per process; 0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=min(16, os.cpu_count() or 1),
+                    help="single-thread oracle processes of the CPU baseline")
     ap.add_argument("--kernel-breakdown", action="store_true", help="one extra untimed step with per-kernel events")
     args = ap.parse_args()
+
+    # CPU baseline first: its workers are spawned, which must not happen once this process holds the GPU
+    cpu = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_planes != 0:
+        cpu = cpu_baseline(args.cpu_planes or 4 * args.cpu_procs, args.cpu_procs)
+        log("[bench] cpu baseline: {}".format(cpu))
 
     dist, rank, world, local = init_dist(args.gpus)
     if world != args.gpus:
@@ -236,8 +276,8 @@ def main():
         }
         if breakdown is not None:
             result["kernel_ms"] = breakdown
-        if world == 1 and args.cpu_planes > 0:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_planes)
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
         os.write(json_fd, (json.dumps(result) + "\n").encode())
 
     d_in.free()
