@@ -50,31 +50,54 @@ def init_dist(n_gpus):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(local)
+    global _HOST_COLLECTIVES
     try:
         dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
     except Exception as e:  # pragma: no cover - environment dependent
         log("[bench] mixed backend init failed ({}); falling back to nccl".format(e))
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        _HOST_COLLECTIVES = False
     return dist, rank, world, local
 
 
+_HOST_COLLECTIVES = True  # the group has a gloo side: barriers / time reduction stay off the device
+
+
+def host_all_reduce(dist, values, op=None):
+    """All-reduce of a few scalars over the ranks (gloo when the group has it, else through the device)."""
+    import torch
+
+    t = torch.tensor(values, dtype=torch.float64)
+    if not _HOST_COLLECTIVES:
+        t = t.cuda()
+    dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
+    return [float(x) for x in t.cpu()]
+
+
 def broadcast_constants(dist, engine, rank):
-    """RCCL broadcast (root 0) of the filter-constant blob: twiddles + per-level gain tables."""
+    """RCCL broadcast (root 0) of the filter-constant blob: twiddles + per-level gain tables.
+
+    Every rank has already planned the same constants, so a failing collective (a node without working
+    xGMI / RCCL) is logged and does not stop the data path, which never communicates."""
     import ctypes
 
     import torch
 
     ptr, nbytes = engine.constants_device()
-    buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    lib, ctx = engine._lib, engine._ctx
-    if rank == 0:
-        lib.dsx_memcpy_d2d(ctx, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(ptr), nbytes)
-        engine.sync()
-    dist.broadcast(buf, src=0)
-    torch.cuda.synchronize()
-    if rank != 0:
-        lib.dsx_memcpy_d2d(ctx, ctypes.c_void_p(ptr), ctypes.c_void_p(buf.data_ptr()), nbytes)
-        engine.sync()
+    try:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        lib, ctx = engine._lib, engine._ctx
+        if rank == 0:
+            lib.dsx_memcpy_d2d(ctx, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(ptr), nbytes)
+            engine.sync()
+        dist.broadcast(buf, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            lib.dsx_memcpy_d2d(ctx, ctypes.c_void_p(ptr), ctypes.c_void_p(buf.data_ptr()), nbytes)
+            engine.sync()
+    except Exception as e:  # pragma: no cover - needs a multi-GPU node
+        log("[bench] rank {}: constants broadcast failed ({}); using the locally planned constants".format(rank, e))
+        return 0
     return nbytes
 
 
@@ -188,7 +211,7 @@ def main():
             import torch
 
             torch.cuda.synchronize()
-            dist.barrier()
+            host_all_reduce(dist, [0.0])  # barrier on the gloo side of the group
 
     for _ in range(args.warmup):
         step()
@@ -202,11 +225,7 @@ def main():
     wall = time.perf_counter() - t_start
 
     if dist is not None:
-        import torch
-
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(t[0]), float(t[1])
+        wall, dev_ms = host_all_reduce(dist, [wall, dev_ms], op=dist.ReduceOp.MAX)
 
     # sanity on the result of the last step: config branch per plane and a checksum
     cfg = d_cfg.download((args.batch,), np.int32)
@@ -285,7 +304,7 @@ def main():
     d_cfg.free()
     engine.close()
     if dist is not None:
-        dist.barrier()
+        host_all_reduce(dist, [0.0])
         dist.destroy_process_group()
 
 
