@@ -61,30 +61,84 @@ inline int dwt_max_level(int n) {
   return l < 0 ? 0 : l;
 }
 
-// Radix list of a length: composite register butterflies first (fewer Stockham passes), then the
-// small primes, the odd-prime register butterflies (7..19) and, for anything else, generic passes.
-inline std::vector<int> factorize(int n) {
-  std::vector<int> r;
-  int a = 0, b = 0, c = 0;  // powers of 2, 3, 5
-  while (n % 2 == 0) { ++a; n /= 2; }
-  while (n % 3 == 0) { ++b; n /= 3; }
-  while (n % 5 == 0) { ++c; n /= 5; }
-  while (a >= 4) { r.push_back(16); a -= 4; }
-  while (b >= 2) { r.push_back(9); b -= 2; }
-  while (c >= 2) { r.push_back(25); c -= 2; }
-  if (a == 3) { r.push_back(8); a = 0; }
-  if (a >= 1 && b >= 1) { r.push_back(6); --a; --b; }
-  if (a >= 2 && c >= 1) { r.push_back(20); a -= 2; --c; }
-  if (a >= 2 && b >= 1) { r.push_back(12); a -= 2; --b; }
-  if (a >= 1 && c >= 1) { r.push_back(10); --a; --c; }
-  if (b >= 1 && c >= 1) { r.push_back(15); --b; --c; }
-  while (a >= 2) { r.push_back(4); a -= 2; }
-  while (a >= 1) { r.push_back(2); --a; }
-  while (b >= 1) { r.push_back(3); --b; }
-  while (c >= 1) { r.push_back(5); --c; }
-  for (int p = 7; n > 1; p += 2) {
-    while (n % p == 0) { r.push_back(p); n /= p; }
+// kernel instantiations of k_rowfilter: complex values per lane (register budget / occupancy)
+inline int cpl_class(int m) {
+  const int cpl = (m + 63) / 64;
+  for (int c : {2, 4, 6, 10, 18, 36}) if (cpl <= c) return c;
+  return 1 << 30;
+}
+
+// Register-butterfly radices of k_rowfilter and the VALU instructions of one "round" of a pass
+// (64 butterflies, one per lane; measured on the gfx950 code of the CPL = 18 instantiation, rocm 7.2).
+// A pass over M values runs ceil(M / R / 64) rounds, so a radix whose butterfly count is just above
+// a multiple of 64 pays a whole round for a few lanes (R = 16 at M = 1152: 72 butterflies, 2 rounds).
+constexpr int kRegRadix[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 19, 20, 25};
+inline double round_cost(int r) {
+  switch (r) {
+    case 2: return 28;
+    case 3: return 37;
+    case 4: return 64;
+    case 5: return 84;
+    case 6: return 82;
+    case 7: return 109;
+    case 8: return 133;
+    case 9: return 151;
+    case 10: return 214;
+    case 11: return 191;
+    case 12: return 251;
+    case 13: return 238;
+    case 15: return 352;
+    case 16: return 337;
+    case 17: return 359;
+    case 19: return 408;
+    case 20: return 520;
+    case 25: return 708;
+    default: return 64.0 * (8.0 + 10.0 * r);  // generic pass: O(R) per value
   }
+}
+// cost of one pass of radix r inside a length-m transform (+ a fixed part per pass: two wave-level LDS
+// fences and the exposed LDS latency)
+inline double pass_cost(int m, int r) {
+  constexpr double kPerPass = 60.0;
+  bool reg = false;
+  for (int q : kRegRadix) reg = reg || (q == r);
+  if (!reg) return kPerPass + round_cost(r) * ((m + 63) / 64) / (double)r;  // one value per lane and round
+  return kPerPass + round_cost(r) * (double)((m / r + 63) / 64);
+}
+
+// Cheapest decomposition of m into passes: dynamic programme over the divisors of m (the cost of a
+// pass depends on m and its radix only, not on the order).  Prime factors above 19 go through the
+// generic pass.
+inline void best_passes(int m, int rest, std::vector<int>& cur, double cost, std::vector<int>& best,
+                        double& best_cost) {
+  if (cost >= best_cost || (int)cur.size() > kPlanMaxPasses) return;
+  if (rest == 1) { best = cur; best_cost = cost; return; }
+  bool any = false;
+  const int last = cur.empty() ? 1 << 30 : cur.back();
+  for (int i = (int)(sizeof(kRegRadix) / sizeof(int)) - 1; i >= 0; --i) {
+    const int r = kRegRadix[i];
+    if (rest % r) continue;
+    any = true;
+    if (r > last) continue;  // non-increasing order: every multiset is visited once
+    cur.push_back(r);
+    best_passes(m, rest / r, cur, cost + pass_cost(m, r), best, best_cost);
+    cur.pop_back();
+  }
+  if (!any) {  // a prime factor without a register butterfly
+    int pr = rest;
+    for (int q = 2; q * q <= rest; ++q) if (rest % q == 0) { pr = q; break; }
+    cur.push_back(pr);
+    best_passes(m, rest / pr, cur, cost + pass_cost(m, pr), best, best_cost);
+    cur.pop_back();
+  }
+}
+
+// Radix list of a length, in pass order.
+inline std::vector<int> factorize(int n, double* cost_out = nullptr) {
+  std::vector<int> r, cur;
+  double best = 1e300;
+  if (n > 1) best_passes(n, n, cur, 0.0, r, best);
+  else best = 0.0;
   // Pass order = LDS bank behaviour: the first pass scatters with stride R (buf[R b + k]) and gathers
   // twiddles tw[b k]; a power-of-two R puts whole lane groups on one bank (16-way conflicts for
   // R = 16).  Radices with an odd factor go first, pure powers of two last (their stride is then
@@ -93,45 +147,17 @@ inline std::vector<int> factorize(int n) {
     const bool pa = (a & (a - 1)) == 0, pb = (b & (b - 1)) == 0;
     return !pa && pb;
   });
+  if (cost_out) *cost_out = best;
   return r;
 }
 
-// relative cost of one pass per element (register butterflies vs the generic O(R) pass)
-inline double pass_cost(int r) {
-  switch (r) {
-    case 2: return 10.0;
-    case 3: return 13.3;
-    case 4: return 12.0;
-    case 5: return 16.0;
-    case 6: return 15.0;
-    case 8: return 15.0;
-    case 9: return 17.0;
-    case 10: return 19.0;
-    case 12: return 18.0;
-    case 15: return 22.0;
-    case 16: return 18.0;
-    case 20: return 22.0;
-    case 25: return 26.0;
-    case 7: return 22.0;
-    case 11: return 32.0;
-    case 13: return 38.0;
-    case 17: return 50.0;
-    case 19: return 56.0;
-    default: return 8.0 + 10.0 * r;
-  }
-}
-// kernel instantiations of k_rowfilter: complex values per lane (register budget / occupancy)
-inline int cpl_class(int m) {
-  const int cpl = (m + 63) / 64;
-  for (int c : {2, 4, 6, 10, 18, 36}) if (cpl <= c) return c;
-  return 1 << 30;
-}
 inline double fft_cost(int m) {
   double c = 0;
-  for (int r : factorize(m)) c += pass_cost(r);
+  factorize(m, &c);
   // the 36-per-lane instantiation runs at one wave per SIMD: roughly 3x slower per instruction
   const double occ = (cpl_class(m) > 18) ? 3.0 : 1.0;
-  return c * m * occ;
+  // everything outside the passes (keys, median, in-paint, spectral step, row I/O) scales with m
+  return (c + 30.0 * ((m + 63) / 64)) * occ;
 }
 
 // LP gains in fftpack packed order, folded to the complex bins of a length-n transform:
@@ -212,8 +238,8 @@ inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p) {
       const double s = lp.h * (cfg[c].sigma / min_hw);  // filtering.py:180, 213
       packed_gains(n, s, ep[c], em[c]);
     }
-    // Candidates: (a) the direct length-n transform (generic O(R) passes for prime factors > 5);
-    // (b) the exact embedding of the length-n circular operator in a 2-3-5-smooth length
+    // Candidates: (a) the direct length-n transform (generic O(R) passes for prime factors > 19);
+    // (b) the exact embedding of the length-n circular operator in a 19-smooth length
     //     M >= n + 2K + 1 with a periodic halo of K = floor(n / 2) samples on both sides.
     //     (The spatial kernels of ep / em decay only like 1/d^2 -- the packed-index gains are not
     //      smooth at k = 0 -- so the halo cannot be truncated below n / 2.)
@@ -225,8 +251,8 @@ inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p) {
       const int need = n + 2 * K + 1;
       for (int m = need; m <= std::min(2 * need, kMaxFftLen); ++m) {
         int t = m;
-        for (int q : {2, 3, 5}) while (t % q == 0) t /= q;
-        if (t != 1) continue;
+        for (int q : {2, 3, 5, 7, 11, 13, 17, 19}) while (t % q == 0) t /= q;
+        if (t != 1) continue;  // only lengths whose passes all have register butterflies
         const double c = fft_cost(m);
         if (c < best_cost) { best_cost = c; best_m = m; best_k = K; }
       }
