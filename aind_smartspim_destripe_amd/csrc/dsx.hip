@@ -162,13 +162,13 @@ int rowfilter_waves_per_block(int M) {
   return best_w;
 }
 
-template <int CPL>
+template <int CPL, int GF = -1, int NT = -1>
 hipError_t launch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s) {
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_set[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)dsx::k_rowfilter<CPL>,
+    hipError_t e = hipFuncSetAttribute((const void*)dsx::k_rowfilter<CPL, GF, NT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev & 63] = true;
@@ -177,7 +177,7 @@ hipError_t launch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream
   const int wpb = force_wpb ? force_wpb : ((CPL > 18) ? 4 : rowfilter_waves_per_block(a.M));
   const size_t smem = (size_t)a.M * (wpb + 1) * sizeof(float2);
   dim3 grid((npairs + wpb - 1) / wpb, nb);
-  hipLaunchKernelGGL(dsx::k_rowfilter<CPL>, grid, dim3(64 * wpb), smem, s, a);
+  hipLaunchKernelGGL((dsx::k_rowfilter<CPL, GF, NT>), grid, dim3(64 * wpb), smem, s, a);
   return hipGetLastError();
 }
 
@@ -187,7 +187,14 @@ hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStre
   if (cpl <= 4) return launch_rowfilter<4>(a, npairs, nb, s);
   if (cpl <= 6) return launch_rowfilter<6>(a, npairs, nb, s);
   if (cpl <= 10) return launch_rowfilter<10>(a, npairs, nb, s);
-  if (cpl <= 18) return launch_rowfilter<18>(a, npairs, nb, s);
+  if (cpl <= 18) {
+    // slot structure of the row (full 256-value groups, 64-value tail slots): the shapes of a 2048-wide
+    // plane (levels 1 and 2: 1026 and 515 values) run without the per-group guards
+    const int gf = a.w >> 8, nt = (a.w - (gf << 8) + 63) >> 6;
+    if (gf == 4 && nt == 1) return launch_rowfilter<18, 4, 1>(a, npairs, nb, s);
+    if (gf == 2 && nt == 1) return launch_rowfilter<18, 2, 1>(a, npairs, nb, s);
+    return launch_rowfilter<18>(a, npairs, nb, s);
+  }
   return launch_rowfilter<36>(a, npairs, nb, s);
 }
 

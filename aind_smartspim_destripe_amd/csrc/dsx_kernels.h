@@ -740,27 +740,61 @@ __device__ __forceinline__ unsigned as_u32(dsx_s16x2 v) {
   return c.u;
 }
 
+// ---- element slots of a lane ------------------------------------------------------------------------
+// A row of N values is split into Gf = N / 256 full groups (slot 4 g + i of a lane = element
+// 256 g + 4 lane + i: one 16-byte access per group and row) and T = ceil((N % 256) / 64) lane-strided
+// tail slots (slot 4 GV + k = element 256 Gf + 64 k + lane).  Only Gf groups and T tail slots are
+// executed (wave-uniform guards), so a row of 1026 values costs 17 slots per lane and one of 515
+// values 9 -- not the 20 the register arrays are dimensioned for.
+template <int CPL>
+struct RowSlots {
+  static constexpr int GV = CPL / 4;     // vector groups the class can hold (N <= 64 CPL)
+  static constexpr int E = 4 * GV + 4;   // register slots: vector groups + 4 tail slots
+};
+template <int E>
+struct SlotMask { typedef unsigned long long type; };
+template <> struct SlotMask<4> { typedef unsigned type; };
+template <> struct SlotMask<8> { typedef unsigned type; };
+template <> struct SlotMask<12> { typedef unsigned type; };
+template <> struct SlotMask<20> { typedef unsigned type; };
+
+// f(e) for every active slot e (e is a compile-time constant after unrolling)
+template <int GV, typename F>
+__device__ __forceinline__ void for_slots(int gf, int nt, F&& f) {
+#pragma unroll
+  for (int g = 0; g < GV; ++g) {
+    if (g < gf) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f(4 * g + i);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < nt) f(4 * GV + k);
+  }
+}
+
 // Per-lane count of packed 16-bit values below a packed threshold, both halves at once:
 // x and t are in signed order (value ^ 0x8000); returns {#(x.lo < t.lo), #(x.hi < t.hi)} packed.
-template <int E>
-__device__ __forceinline__ unsigned count_below_pk16(const unsigned (&x)[E], unsigned t) {
+template <int GV, int E>
+__device__ __forceinline__ unsigned count_below_pk16(const unsigned (&x)[E], unsigned t, int gf, int nt) {
   const dsx_s16x2 tv = as_s16x2(t);
   dsx_s16x2 acc = as_s16x2(0u);
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
+  for_slots<GV>(gf, nt, [&](int e) {
     const dsx_s16x2 d = __builtin_elementwise_sub_sat(as_s16x2(x[e]), tv);  // < 0  <=>  x < t
     acc -= (d >> 15);                                                       // -1 per hit
-  }
+  });
   return as_u32(acc);
 }
 
 // largest 16-bit T (per half) with #{x < T} <= rank (per half); x in signed order
-template <int E>
-__device__ __forceinline__ unsigned bisect_pk16(const unsigned (&x)[E], unsigned rank_a, unsigned rank_b) {
+template <int GV, int E>
+__device__ __forceinline__ unsigned bisect_pk16(const unsigned (&x)[E], unsigned rank_a, unsigned rank_b,
+                                                int gf, int nt) {
   unsigned ra = 0, rb = 0;
   for (int bit = 15; bit >= 0; --bit) {
     const unsigned ta = ra | (1u << bit), tb = rb | (1u << bit);
-    unsigned c = count_below_pk16<E>(x, (ta | (tb << 16)) ^ 0x80008000u);
+    unsigned c = count_below_pk16<GV, E>(x, (ta | (tb << 16)) ^ 0x80008000u, gf, nt);
     c = __reduce_add_sync(~0ull, c);
     if ((c & 0xFFFFu) <= rank_a) ra = ta;
     if ((c >> 16) <= rank_b) rb = tb;
@@ -777,7 +811,9 @@ constexpr int row_waves_per_simd() {
 constexpr int kRowMaxWaves = 8;  // waves (row pairs) per block; they share one twiddle table
 
 // One wave per pair of rows.  CPL = complex values per lane = ceil(M / 64).
-template <int CPL>
+// GF_ / NT_ >= 0: the slot structure of the row (full groups, tail slots) is a compile-time constant
+// (the hot shapes get their own instantiation without the per-group guards); -1: taken from a.w.
+template <int CPL, int GF_ = -1, int NT_ = -1>
 __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void k_rowfilter(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -794,6 +830,14 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   float* rowa = a.ws + plane * a.ws_plane_stride + a.da_off + (long long)r0 * a.ld;
   float* rowb = rowa + a.ld;
 
+  constexpr int GV = RowSlots<CPL>::GV;
+  constexpr int E = RowSlots<CPL>::E;
+  typedef typename SlotMask<E>::type mask_t;
+  const int gf = (GF_ >= 0) ? GF_ : (N >> 8);                   // full 256-element groups
+  const int tail0 = gf << 8;                                    // first tail element
+  const int nt = (NT_ >= 0) ? NT_ : ((N - tail0 + 63) >> 6);    // lane-strided tail slots
+  const int tn = tail0 + lane;                 // this lane's element of tail slot 0 (+ 64 per slot)
+
   if (a.lvl >= a.lvl_active[cfg]) {  // this config does not filter this level: Delta = 0 (block-uniform)
     if (live) {
       for (int n = 4 * lane; n < N; n += 4 * kWave) {
@@ -806,49 +850,59 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   const float thr = a.thr[(long long)plane * a.L + a.lvl];
 
   // ---- load both rows; background = masked entries zeroed (filtering.py:195-197) -------------
-  // Element slot e = 4 g + i of a lane is row element n = 256 g + 4 lane + i: one 16-byte load per
-  // group g (rows are 16-byte aligned, pitch a multiple of 4 floats).
-  // Order-preserving 32-bit keys, split into packed 16-bit halves {row a | row b << 16}:
-  // hs = high halves, ls = low halves, both in signed order (^ 0x8000) for the saturating compare.
-  constexpr int G = (CPL + 3) / 4;
-  constexpr int E = 4 * G;
   // issue the row loads, THEN stage the twiddles: the two global latencies overlap
-  float4 ra4[G], rb4[G];
+  float4 ra4[GV > 0 ? GV : 1], rb4[GV > 0 ? GV : 1];
+  float rta[4], rtb[4];
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int nb0 = 256 * g + 4 * lane;
+  for (int g = 0; g < GV; ++g) {
     ra4[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     rb4[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live && nb0 < N) {  // nb0 + 3 < ld: the pitch is N rounded up to a multiple of 4 (plus spare)
-      ra4[g] = *(const float4*)(rowa + nb0);
-      if (has_b) rb4[g] = *(const float4*)(rowb + nb0);
+    if (live && g < gf) {
+      ra4[g] = *(const float4*)(rowa + 256 * g + 4 * lane);
+      if (has_b) rb4[g] = *(const float4*)(rowb + 256 * g + 4 * lane);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    rta[k] = 0.f;
+    rtb[k] = 0.f;
+    if (live && k < nt && tn + 64 * k < N) {
+      rta[k] = rowa[tn + 64 * k];
+      if (has_b) rtb[k] = rowb[tn + 64 * k];
     }
   }
   for (int i = tid; i < M; i += blockDim.x) s_tw[i] = a.tw[i];
   __syncthreads();  // the only block-wide barrier: afterwards every wave works on its own rows
   if (!live) return;
 
+  // Order-preserving 32-bit keys, split into packed 16-bit halves {row a | row b << 16}:
+  // hs = high halves, ls = low halves, both in signed order (^ 0x8000) for the saturating compare.
   unsigned hs[E], ls[E];
-  unsigned long long maska = 0, maskb = 0;
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int nb0 = 256 * g + 4 * lane;
-    const float va[4] = {ra4[g].x, ra4[g].y, ra4[g].z, ra4[g].w};
-    const float vb[4] = {rb4[g].x, rb4[g].y, rb4[g].z, rb4[g].w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = 4 * g + i;
-      unsigned ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;  // padding sorts last
-      if (nb0 + i < N) {
-        const bool ma = fabsf(va[i]) > thr, mb = fabsf(vb[i]) > thr;
-        if (ma) maska |= (1ull << e);
-        if (mb) maskb |= (1ull << e);
-        ka = f32_key(ma ? 0.f : va[i]);
-        kb = f32_key(mb ? 0.f : vb[i]);
-      }
-      hs[e] = ((ka >> 16) | (kb & 0xFFFF0000u)) ^ 0x80008000u;
-      ls[e] = ((ka & 0xFFFFu) | (kb << 16)) ^ 0x80008000u;
+  mask_t maska = 0, maskb = 0;
+  auto make_keys = [&](int e, float va, float vb, bool valid) {
+    unsigned ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;  // padding sorts last
+    if (valid) {
+      const bool ma = fabsf(va) > thr, mb = fabsf(vb) > thr;
+      if (ma) maska |= ((mask_t)1 << e);
+      if (mb) maskb |= ((mask_t)1 << e);
+      ka = f32_key(ma ? 0.f : va);
+      kb = f32_key(mb ? 0.f : vb);
     }
+    hs[e] = ((ka >> 16) | (kb & 0xFFFF0000u)) ^ 0x80008000u;
+    ls[e] = ((ka & 0xFFFFu) | (kb << 16)) ^ 0x80008000u;
+  };
+#pragma unroll
+  for (int g = 0; g < GV; ++g) {
+    if (g < gf) {
+      make_keys(4 * g + 0, ra4[g].x, rb4[g].x, true);
+      make_keys(4 * g + 1, ra4[g].y, rb4[g].y, true);
+      make_keys(4 * g + 2, ra4[g].z, rb4[g].z, true);
+      make_keys(4 * g + 3, ra4[g].w, rb4[g].w, true);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < nt) make_keys(4 * GV + k, rta[k], rtb[k], tn + 64 * k < N);
   }
 
   // ---- exact row medians (np.median, filtering.py:201) ------------------------------------------
@@ -856,21 +910,20 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   // the low half over the elements that share the selected high half.
   float meda = 0.f, medb = 0.f;
   // the medians only enter through the masked positions: skip them for a mask-free pair of rows
-  const bool any_mask = __ballot((maska | maskb) != 0ull) != 0ull;
+  const bool any_mask = __ballot((maska | maskb) != (mask_t)0) != 0ull;
   if (any_mask && !(a.ablate & 1)) {
   const unsigned k1 = (unsigned)(N - 1) >> 1;
-  const unsigned rhi = bisect_pk16<E>(hs, k1, k1);
-  unsigned below = __reduce_add_sync(~0ull, count_below_pk16<E>(hs, rhi ^ 0x80008000u));
+  const unsigned rhi = bisect_pk16<GV, E>(hs, k1, k1, gf, nt);
+  unsigned below = __reduce_add_sync(~0ull, count_below_pk16<GV, E>(hs, rhi ^ 0x80008000u, gf, nt));
   // Low halves of the candidates (elements whose high half equals the selected one), in unsigned
   // order; all other elements get the maximum 0xFFFF.
   unsigned lsel[E];
   {
     const dsx_s16x2 rv = as_s16x2(rhi ^ 0x80008000u);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
+    for_slots<GV>(gf, nt, [&](int e) {
       const dsx_s16x2 eq = (as_s16x2(hs[e]) == rv);  // -1 where the high half matches
       lsel[e] = ((ls[e] ^ 0x80008000u) & as_u32(eq)) | ~as_u32(eq);
-    }
+    });
   }
   // Rank inside the bucket.  The bucket is usually tiny (a 2^-7 relative slice of the value range),
   // so walk its distinct values in ascending order: next value = lower bound + wave-min of the
@@ -888,12 +941,11 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
     union U { unsigned u; dsx_u16x2 v; };
     U lbv; lbv.u = lb;
     U mn; mn.u = 0xFFFFFFFFu;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
+    for_slots<GV>(gf, nt, [&](int e) {
       U x; x.u = lsel[e];
       U d; d.v = x.v - lbv.v;  // elements below the bound wrap around to large values
       mn.v = __builtin_elementwise_min(mn.v, d.v);
-    }
+    });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       U t; t.u = (unsigned)__shfl_xor((int)mn.u, o);
@@ -903,12 +955,11 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
     // multiplicity of that value: count zero differences
     U cnt; cnt.u = 0;
     const dsx_u16x2 one = {1, 1};
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
+    for_slots<GV>(gf, nt, [&](int e) {
       U x; x.u = lsel[e];
       U z; z.v = x.v - val.v;
       cnt.v += one - __builtin_elementwise_min(z.v, one);
-    }
+    });
     const unsigned c = __reduce_add_sync(~0ull, cnt.u);
     const unsigned va = val.u & 0xFFFFu, vb = val.u >> 16;
     if (!done_a) {
@@ -926,9 +977,8 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   if (!all_done) {
     // dense bucket: bisection of the low half (signed-order operands, sentinel never counted)
     unsigned lsg[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) lsg[e] = lsel[e] ^ 0x80008000u;
-    const unsigned r2 = bisect_pk16<E>(lsg, k1 - (below & 0xFFFFu), k1 - (below >> 16));
+    for_slots<GV>(gf, nt, [&](int e) { lsg[e] = lsel[e] ^ 0x80008000u; });
+    const unsigned r2 = bisect_pk16<GV, E>(lsg, k1 - (below & 0xFFFFu), k1 - (below >> 16), gf, nt);
     if (!__builtin_amdgcn_readfirstlane(done_a)) rlo = (rlo & 0xFFFF0000u) | (r2 & 0xFFFFu);
     if (!__builtin_amdgcn_readfirstlane(done_b)) rlo = (rlo & 0xFFFFu) | (r2 & 0xFFFF0000u);
   }
@@ -939,8 +989,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   if ((N & 1) == 0) {
     // second middle order statistic: the smallest key above the first one unless the first is tied
     unsigned c = 0, mna = 0xFFFFFFFFu, mnb = 0xFFFFFFFFu;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
+    for_slots<GV>(gf, nt, [&](int e) {
       const unsigned h = hs[e] ^ 0x80008000u, l = ls[e] ^ 0x80008000u;
       const unsigned ka = (h << 16) | (l & 0xFFFFu);
       const unsigned kb = (h & 0xFFFF0000u) | (l >> 16);
@@ -948,7 +997,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
       c += (kb <= keyb) ? 0x10000u : 0u;
       if (ka > keya) mna = min(mna, ka);
       if (kb > keyb) mnb = min(mnb, kb);
-    }
+    });
     c = __reduce_add_sync(~0ull, c);
     // cross-lane minimum through an LDS atomic (once per row pair); the row buffer is still unused
     unsigned* s_mn = (unsigned*)buf;
@@ -971,13 +1020,12 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   asm volatile("" : "+v"(meda), "+v"(medb));
 
   // ---- in-painted rows -> complex buffer u[m] = x[(m - K) mod N], m in [0, N + 2K]; zero above -----
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int n = 256 * (e >> 2) + 4 * lane + (e & 3);
-    if (n < N) {
+  for_slots<GV>(gf, nt, [&](int e) {
+    const int n = (e < 4 * GV) ? 256 * (e >> 2) + 4 * lane + (e & 3) : tn + 64 * (e - 4 * GV);
+    if (e < 4 * GV || n < N) {
       const unsigned h = hs[e] ^ 0x80008000u, l = ls[e] ^ 0x80008000u;
-      const float xa = ((maska >> e) & 1ull) ? meda : key_f32((h << 16) | (l & 0xFFFFu));
-      const float xb = ((maskb >> e) & 1ull) ? medb : key_f32((h & 0xFFFF0000u) | (l >> 16));
+      const float xa = ((maska >> e) & (mask_t)1) ? meda : key_f32((h << 16) | (l & 0xFFFFu));
+      const float xb = ((maskb >> e) & (mask_t)1) ? medb : key_f32((h & 0xFFFF0000u) | (l >> 16));
       const float2 z = make_float2(xa, xb);
       buf[K + n] = z;
       if (K > 0) {
@@ -985,7 +1033,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
         if (n >= N - K) buf[n - (N - K)] = z;
       }
     }
-  }
+  });
   if (K > 0) {
     for (int m = N + 2 * K + 1 + lane; m < M; m += kWave) buf[m] = make_float2(0.f, 0.f);
   }
@@ -1016,20 +1064,29 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
 
   // ---- buf = swap(M * LP): row a <- .y, row b <- .x ; Delta = -(1 - mask) LP (filtering.py:215-217)
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int nb0 = 256 * g + 4 * lane;
-    if (nb0 < N) {
+  for (int g = 0; g < GV; ++g) {
+    if (g < gf) {
+      const int nb0 = 256 * g + 4 * lane;
       float da_[4], db_[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int e = 4 * g + i;
-        const float2 y = (nb0 + i < N) ? buf[K + nb0 + i] : make_float2(0.f, 0.f);
-        da_[i] = ((maska >> e) & 1ull) ? 0.f : -y.y * a.inv_M;
-        db_[i] = ((maskb >> e) & 1ull) ? 0.f : -y.x * a.inv_M;
+        const float2 y = buf[K + nb0 + i];
+        da_[i] = ((maska >> e) & (mask_t)1) ? 0.f : -y.y * a.inv_M;
+        db_[i] = ((maskb >> e) & (mask_t)1) ? 0.f : -y.x * a.inv_M;
       }
-      // the pitch covers nb0 + 3: pad columns beyond N are never read as data
       *(float4*)(rowa + nb0) = make_float4(da_[0], da_[1], da_[2], da_[3]);
       if (has_b) *(float4*)(rowb + nb0) = make_float4(db_[0], db_[1], db_[2], db_[3]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int n = tn + 64 * k;
+    if (k < nt && n < N) {
+      const int e = 4 * GV + k;
+      const float2 y = buf[K + n];
+      rowa[n] = ((maska >> e) & (mask_t)1) ? 0.f : -y.y * a.inv_M;
+      if (has_b) rowb[n] = ((maskb >> e) & (mask_t)1) ? 0.f : -y.x * a.inv_M;
     }
   }
 }
