@@ -162,13 +162,13 @@ int rowfilter_waves_per_block(int M) {
   return best_w;
 }
 
-template <int CPL, int GF = -1, int NT = -1>
+template <int CPL, int GF = -1, int NT = -1, int HALO = -1, int PLAN = 0>
 hipError_t launch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s) {
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_set[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)dsx::k_rowfilter<CPL, GF, NT>,
+    hipError_t e = hipFuncSetAttribute((const void*)dsx::k_rowfilter<CPL, GF, NT, HALO, PLAN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev & 63] = true;
@@ -177,7 +177,7 @@ hipError_t launch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream
   const int wpb = force_wpb ? force_wpb : ((CPL > 18) ? 4 : rowfilter_waves_per_block(a.M));
   const size_t smem = (size_t)a.M * (wpb + 1) * sizeof(float2);
   dim3 grid((npairs + wpb - 1) / wpb, nb);
-  hipLaunchKernelGGL((dsx::k_rowfilter<CPL, GF, NT>), grid, dim3(64 * wpb), smem, s, a);
+  hipLaunchKernelGGL((dsx::k_rowfilter<CPL, GF, NT, HALO, PLAN>), grid, dim3(64 * wpb), smem, s, a);
   return hipGetLastError();
 }
 
@@ -191,8 +191,17 @@ hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStre
     // slot structure of the row (full 256-value groups, 64-value tail slots): the shapes of a 2048-wide
     // plane (levels 1 and 2: 1026 and 515 values) run without the per-group guards
     const int gf = a.w >> 8, nt = (a.w - (gf << 8) + 63) >> 6;
-    if (gf == 4 && nt == 1) return launch_rowfilter<18, 4, 1>(a, npairs, nb, s);
-    if (gf == 2 && nt == 1) return launch_rowfilter<18, 2, 1>(a, npairs, nb, s);
+    auto plan_is = [&](int m, int r0, int r1, int r2) {
+      return a.M == m && a.npass == 3 && a.radix[0] == r0 && a.radix[1] == r1 && a.radix[2] == r2;
+    };
+    if (gf == 4 && nt == 1 && a.K == 0) {
+      if (plan_is(1026, 19, 9, 6)) return launch_rowfilter<18, 4, 1, 0, 1>(a, npairs, nb, s);
+      return launch_rowfilter<18, 4, 1, 0>(a, npairs, nb, s);
+    }
+    if (gf == 2 && nt == 1 && a.K > 0) {
+      if (plan_is(1071, 17, 9, 7)) return launch_rowfilter<18, 2, 1, 1, 2>(a, npairs, nb, s);
+      return launch_rowfilter<18, 2, 1, 1>(a, npairs, nb, s);
+    }
     return launch_rowfilter<18>(a, npairs, nb, s);
   }
   return launch_rowfilter<36>(a, npairs, nb, s);

@@ -727,6 +727,39 @@ __device__ __forceinline__ void fft_run(float2* buf, const float2* tw, const Row
   }
 }
 
+// Compile-time pass lists for the hot lengths: M, the strides and the butterfly counts become
+// constants, so LDS offsets turn into immediates and the b < nb guards fold away.
+template <int CPL, int M_, int S_, int R, int... REST>
+__device__ __forceinline__ void fft_static_passes(float2* buf, const float2* tw, int lane_in) {
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));  // per-pass copy: keeps one pass's address arithmetic out of the next
+  fft_pass<R, CPL>(buf, tw, M_, S_, 1.0f / (float)S_, lane);
+  if constexpr (sizeof...(REST) > 0) fft_static_passes<CPL, M_, S_ * R, REST...>(buf, tw, lane_in);
+}
+// PLAN_ ids of k_rowfilter: 0 = passes from RowArgs; the others must match dsx.hip's dispatch.
+template <int PLAN_>
+struct StaticFft {
+  static constexpr int M = 0;
+};
+template <>
+struct StaticFft<1> {  // level 1 of a 2048-wide plane
+  static constexpr int M = 1026;
+  static constexpr int kRadix[3] = {19, 9, 6};
+  template <int CPL>
+  static __device__ __forceinline__ void run(float2* buf, const float2* tw, int lane) {
+    fft_static_passes<CPL, 1026, 1, 19, 9, 6>(buf, tw, lane);
+  }
+};
+template <>
+struct StaticFft<2> {  // level 2 of a 2048-wide plane: 515 values embedded in 1071
+  static constexpr int M = 1071;
+  static constexpr int kRadix[3] = {17, 9, 7};
+  template <int CPL>
+  static __device__ __forceinline__ void run(float2* buf, const float2* tw, int lane) {
+    fft_static_passes<CPL, 1071, 1, 17, 9, 7>(buf, tw, lane);
+  }
+};
+
 typedef short dsx_s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ dsx_s16x2 as_s16x2(unsigned u) {
@@ -813,11 +846,15 @@ constexpr int kRowMaxWaves = 8;  // waves (row pairs) per block; they share one 
 // One wave per pair of rows.  CPL = complex values per lane = ceil(M / 64).
 // GF_ / NT_ >= 0: the slot structure of the row (full groups, tail slots) is a compile-time constant
 // (the hot shapes get their own instantiation without the per-group guards); -1: taken from a.w.
-template <int CPL, int GF_ = -1, int NT_ = -1>
+// HALO_: 0 = direct transform (K == 0), 1 = periodic halo (K > 0), -1 = decided at run time.
+// PLAN_: compile-time FFT plan (StaticFft), 0 = the pass list of RowArgs.
+template <int CPL, int GF_ = -1, int NT_ = -1, int HALO_ = -1, int PLAN_ = 0>
 __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void k_rowfilter(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int M = a.M, N = a.w, K = a.K;
+  const int M = (PLAN_ > 0) ? StaticFft<PLAN_>::M : a.M;
+  const int N = a.w, K = (HALO_ == 0) ? 0 : a.K;
+  const bool halo = (HALO_ >= 0) ? (HALO_ != 0) : (K > 0);
   float2* s_tw = dsx_smem;
   float2* buf = dsx_smem + (long long)M * (1 + wave);
   const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -1028,18 +1065,21 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
       const float xb = ((maskb >> e) & (mask_t)1) ? medb : key_f32((h & 0xFFFF0000u) | (l >> 16));
       const float2 z = make_float2(xa, xb);
       buf[K + n] = z;
-      if (K > 0) {
+      if (halo) {
         if (n <= K) buf[K + N + n] = z;
         if (n >= N - K) buf[n - (N - K)] = z;
       }
     }
   });
-  if (K > 0) {
+  if (halo) {
     for (int m = N + 2 * K + 1 + lane; m < M; m += kWave) buf[m] = make_float2(0.f, 0.f);
   }
   wave_sync();
 
-  if (!(a.ablate & 2)) fft_run<CPL>(buf, s_tw, a, lane);
+  if (!(a.ablate & 2)) {
+    if constexpr (PLAN_ > 0) StaticFft<PLAN_>::template run<CPL>(buf, s_tw, lane);
+    else fft_run<CPL>(buf, s_tw, a, lane);
+  }
 
   // ---- V[k] = G1[k] U[k] + G2[k] U[M - k], in place on the pair (k, M - k) ---------------------
   // G1 is real and even, G2[M - k] = conj(G2[k]) (both modes, dsx_plan.h).  The result is stored
@@ -1060,7 +1100,10 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
     wave_sync();
   }
 
-  if (!(a.ablate & 2)) fft_run<CPL>(buf, s_tw, a, lane);
+  if (!(a.ablate & 2)) {
+    if constexpr (PLAN_ > 0) StaticFft<PLAN_>::template run<CPL>(buf, s_tw, lane);
+    else fft_run<CPL>(buf, s_tw, a, lane);
+  }
 
   // ---- buf = swap(M * LP): row a <- .y, row b <- .x ; Delta = -(1 - mask) LP (filtering.py:215-217)
 #pragma unroll
