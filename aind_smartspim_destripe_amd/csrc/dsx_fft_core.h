@@ -18,14 +18,24 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define DSX_HD __host__ __device__ __forceinline__
-typedef float2 dsx_c32;
+// (re, im) as a 2-vector: element-wise arithmetic maps onto the packed FP32 instructions
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).  Written with scalar members, hipcc's SLP vectoriser
+// pairs unrelated values and shuffles them together with v_mov (20 % of the FFT instructions).
+typedef float dsx_c32 __attribute__((ext_vector_type(2)));
+DSX_HD dsx_c32 dsx_mk(float re, float im) { return dsx_c32{re, im}; }
+DSX_HD dsx_c32 dsx_add(dsx_c32 a, dsx_c32 b) { return a + b; }
+DSX_HD dsx_c32 dsx_sub(dsx_c32 a, dsx_c32 b) { return a - b; }
+// a * (-i)
+DSX_HD dsx_c32 dsx_mul_mi(dsx_c32 a) { return dsx_c32{a.y, -a.x}; }
+DSX_HD dsx_c32 dsx_mul(dsx_c32 a, dsx_c32 b) { return a.xx * b + a.yy * dsx_c32{-b.y, b.x}; }
+DSX_HD dsx_c32 dsx_scale(dsx_c32 a, float s) { return a * s; }
+// a * s + b
+DSX_HD dsx_c32 dsx_fma_s(dsx_c32 a, float s, dsx_c32 b) { return a * s + b; }
 #else
 #define DSX_HD inline
 struct dsx_c32 {
   float x, y;
 };
-#endif
-
 DSX_HD dsx_c32 dsx_mk(float re, float im) {
   dsx_c32 r;
   r.x = re;
@@ -40,6 +50,9 @@ DSX_HD dsx_c32 dsx_mul(dsx_c32 a, dsx_c32 b) {
 // a * (-i)
 DSX_HD dsx_c32 dsx_mul_mi(dsx_c32 a) { return dsx_mk(a.y, -a.x); }
 DSX_HD dsx_c32 dsx_scale(dsx_c32 a, float s) { return dsx_mk(a.x * s, a.y * s); }
+// a * s + b
+DSX_HD dsx_c32 dsx_fma_s(dsx_c32 a, float s, dsx_c32 b) { return dsx_mk(a.x * s + b.x, a.y * s + b.y); }
+#endif
 
 // q = b mod s, via a float reciprocal (exact for b, s < 2^20: the quotient is never within
 // 0.5 / s of an integer, and the relative error of the product is < 2^-22).
@@ -76,7 +89,7 @@ struct dsx_bfly<3> {
     const float S = 0.86602540378443864676f;  // sin(2 pi / 3)
     dsx_c32 t = dsx_add(v[1], v[2]);
     dsx_c32 d = dsx_sub(v[1], v[2]);
-    dsx_c32 u = dsx_mk(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
+    dsx_c32 u = dsx_fma_s(t, -0.5f, v[0]);
     dsx_c32 w = dsx_scale(dsx_mul_mi(d), S);  // -i sin(2pi/3) (x1 - x2)
     v[0] = dsx_add(v[0], t);
     v[1] = dsx_add(u, w);
@@ -108,12 +121,12 @@ struct dsx_bfly<5> {
     dsx_c32 a1 = dsx_add(v[1], v[4]), b1 = dsx_sub(v[1], v[4]);
     dsx_c32 a2 = dsx_add(v[2], v[3]), b2 = dsx_sub(v[2], v[3]);
     dsx_c32 x0 = v[0];
-    v[0] = dsx_mk(x0.x + a1.x + a2.x, x0.y + a1.y + a2.y);
-    dsx_c32 p1 = dsx_mk(x0.x + C1 * a1.x + C2 * a2.x, x0.y + C1 * a1.y + C2 * a2.y);
-    dsx_c32 p2 = dsx_mk(x0.x + C2 * a1.x + C1 * a2.x, x0.y + C2 * a1.y + C1 * a2.y);
+    v[0] = dsx_add(x0, dsx_add(a1, a2));
+    dsx_c32 p1 = dsx_fma_s(a2, C2, dsx_fma_s(a1, C1, x0));
+    dsx_c32 p2 = dsx_fma_s(a2, C1, dsx_fma_s(a1, C2, x0));
     // -i (S1 b1 + S2 b2) and -i (S2 b1 - S1 b2)
-    dsx_c32 q1 = dsx_mul_mi(dsx_mk(S1 * b1.x + S2 * b2.x, S1 * b1.y + S2 * b2.y));
-    dsx_c32 q2 = dsx_mul_mi(dsx_mk(S2 * b1.x - S1 * b2.x, S2 * b1.y - S1 * b2.y));
+    dsx_c32 q1 = dsx_mul_mi(dsx_fma_s(b2, S2, dsx_scale(b1, S1)));
+    dsx_c32 q2 = dsx_mul_mi(dsx_fma_s(b2, -S1, dsx_scale(b1, S2)));
     v[1] = dsx_add(p1, q1);
     v[4] = dsx_sub(p1, q1);
     v[2] = dsx_add(p2, q2);
@@ -255,7 +268,7 @@ DSX_HD void dsx_bfly_odd(dsx_c32* v) {
 #endif
   for (int j = 1; j <= HP; ++j) {
     sp[j - 1] = dsx_add(v[j], v[P - j]);
-    sm[j - 1] = dsx_sub(v[j], v[P - j]);
+    sm[j - 1] = dsx_mul_mi(dsx_sub(v[j], v[P - j]));  // -i (x_j - x_{P-j})
   }
   const dsx_c32 x0 = v[0];
   dsx_c32 dc = x0;
@@ -268,20 +281,16 @@ DSX_HD void dsx_bfly_odd(dsx_c32* v) {
 #pragma unroll
 #endif
   for (int k = 1; k <= HP; ++k) {
-    float ar = x0.x, ai = x0.y, br = 0.f, bi = 0.f;
+    dsx_c32 A = x0, B = dsx_mk(0.f, 0.f);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int j = 1; j <= HP; ++j) {
-      const float c = dsx_root_cos(P, (j * k) % P);
-      const float s = dsx_root_sin(P, (j * k) % P);
-      ar += c * sp[j - 1].x;
-      ai += c * sp[j - 1].y;
-      br += s * sm[j - 1].x;
-      bi += s * sm[j - 1].y;
+      A = dsx_fma_s(sp[j - 1], dsx_root_cos(P, (j * k) % P), A);
+      B = dsx_fma_s(sm[j - 1], dsx_root_sin(P, (j * k) % P), B);
     }
-    v[k] = dsx_mk(ar + bi, ai - br);      // A - iB
-    v[P - k] = dsx_mk(ar - bi, ai + br);  // A + iB
+    v[k] = dsx_add(A, B);      // A - iB'  (B = -i B')
+    v[P - k] = dsx_sub(A, B);  // A + iB'
   }
 }
 template <>
@@ -358,7 +367,7 @@ DSX_HD void dsx_bfly_composite(dsx_c32* v) {
         v[R2 * k1 + n2] = t[k1];
       } else {
         const float c = dsx_root_cos(R, e), sn = -dsx_root_sin(R, e);  // exp(-2 pi i e / R)
-        v[R2 * k1 + n2] = dsx_mk(t[k1].x * c - t[k1].y * sn, t[k1].x * sn + t[k1].y * c);
+        v[R2 * k1 + n2] = dsx_mul(t[k1], dsx_mk(c, sn));
       }
     }
   }
@@ -396,7 +405,7 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
     for (int j = 1; j <= HP; ++j) {
       const dsx_c32 x = v[j], y = v[R - j];
       v[j] = dsx_add(x, y);
-      v[R - j] = dsx_sub(x, y);
+      v[R - j] = dsx_mul_mi(dsx_sub(x, y));  // -i (x_j - x_{R-j})
     }
     const dsx_c32 x0 = v[0];
     dsx_c32 dc = x0;
@@ -409,24 +418,20 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
 #pragma unroll
 #endif
     for (int k = 1; k <= HP; ++k) {
-      float ar = x0.x, ai = x0.y, br = 0.f, bi = 0.f;
+      dsx_c32 A = x0, B = dsx_mk(0.f, 0.f);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
       for (int j = 1; j <= HP; ++j) {
-        const float c = dsx_root_cos(R, (j * k) % R);
-        const float sn = dsx_root_sin(R, (j * k) % R);
-        ar += c * v[j].x;
-        ai += c * v[j].y;
-        br += sn * v[R - j].x;
-        bi += sn * v[R - j].y;
+        A = dsx_fma_s(v[j], dsx_root_cos(R, (j * k) % R), A);
+        B = dsx_fma_s(v[R - j], dsx_root_sin(R, (j * k) % R), B);
       }
       if (unit_tw) {
-        buf[dst + s * k] = dsx_mk(ar + bi, ai - br);        // A - iB
-        buf[dst + s * (R - k)] = dsx_mk(ar - bi, ai + br);  // A + iB
+        buf[dst + s * k] = dsx_add(A, B);        // X[k]   = A - i B'   (B = -i B')
+        buf[dst + s * (R - k)] = dsx_sub(A, B);  // X[R-k] = A + i B'
       } else {
-        buf[dst + s * k] = dsx_mul(dsx_mk(ar + bi, ai - br), tw[ps * k]);
-        buf[dst + s * (R - k)] = dsx_mul(dsx_mk(ar - bi, ai + br), tw[ps * (R - k)]);
+        buf[dst + s * k] = dsx_mul(dsx_add(A, B), tw[ps * k]);
+        buf[dst + s * (R - k)] = dsx_mul(dsx_sub(A, B), tw[ps * (R - k)]);
       }
     }
   } else if constexpr (dsx_comp<R>::R1 != 0) {
@@ -476,8 +481,7 @@ DSX_HD dsx_c32 dsx_generic_output(const dsx_c32* buf, const dsx_c32* tw, int o, 
   for (int j = 0; j < R; ++j) {
     const dsx_c32 x = buf[src];
     const dsx_c32 w = tw[widx];
-    sum.x += x.x * w.x - x.y * w.y;
-    sum.y += x.x * w.y + x.y * w.x;
+    sum = dsx_add(sum, dsx_mul(x, w));
     src += sm;
     widx += wstep;
     if (widx >= M) widx -= M;

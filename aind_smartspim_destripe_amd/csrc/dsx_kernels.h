@@ -654,18 +654,18 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int M, i
   constexpr int MAXB = (CPL + R - 1) / R;
   const int nb = M / R;
   const bool unit_tw = (s * R == M);  // last pass: all twiddles are 1 (wave-uniform)
-  float2 v[MAXB][R];
+  dsx_c32 v[MAXB][R];
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
     const int b = lane + kWave * i;
-    if (b < nb) dsx_bfly_load<R>(buf, b, nb, v[i]);
+    if (b < nb) dsx_bfly_load<R>((const dsx_c32*)buf, b, nb, v[i]);
   }
   // LDS operations of one wave execute in program order: every read above precedes the writes below
   wave_sync();
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
     const int b = lane + kWave * i;
-    if (b < nb) dsx_bfly_store<R>(buf, tw, b, s, inv_s, v[i], unit_tw);
+    if (b < nb) dsx_bfly_store<R>((dsx_c32*)buf, (const dsx_c32*)tw, b, s, inv_s, v[i], unit_tw);
     // keep the unrolled butterflies from being interleaved: their temporaries would all be live
     // at once (215+ VGPRs at 18 values per lane) for no gain -- other waves hide the latency
     __builtin_amdgcn_sched_barrier(0);
@@ -681,7 +681,10 @@ __device__ __forceinline__ void fft_pass_generic(float2* buf, const float2* tw, 
   for (int i = 0; i < CPL; ++i) {
     const int o = lane + kWave * i;
     acc[i] = make_float2(0.f, 0.f);
-    if (o < M) acc[i] = dsx_generic_output(buf, tw, o, M, s, inv_s, R);
+    if (o < M) {
+      const dsx_c32 r = dsx_generic_output((const dsx_c32*)buf, (const dsx_c32*)tw, o, M, s, inv_s, R);
+      acc[i] = make_float2(r.x, r.y);
+    }
   }
   wave_sync();
 #pragma unroll
