@@ -343,6 +343,8 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.tw = (const float2*)(ctx->d_consts + lp.tw_off);
     a.g[0] = (const float2*)(ctx->d_consts + lp.g_off[0]);
     a.g[1] = (const float2*)(ctx->d_consts + lp.g_off[1]);
+    a.kcut[0] = lp.kcut[0];
+    a.kcut[1] = lp.kcut[1];
     a.inv_M = 1.0f / (float)lp.M;
     a.ablate = ctx->ablate;
     const int npairs = (lp.h + 1) / 2;

@@ -636,6 +636,7 @@ struct RowArgs {
   int radix[kMaxPasses];
   const float2* tw;    // [M] exp(-2 pi i t / M)
   const float2* g[2];  // per config: G1[M] then G2[M]
+  int kcut[2];         // per config: the gains vanish for kcut < k < M - kcut
   float inv_M;
   int ablate;          // diagnosis only (DSX_ABLATE): 1 = no median, 2 = no FFT passes, 4 = no spectral step
 };
@@ -1090,7 +1091,8 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   if (!(a.ablate & 4)) {
     const float2* g1 = a.g[cfg];
     const float2* g2 = g1 + M;
-    for (int k = lane; 2 * k <= M; k += kWave) {
+    const int kcut = a.kcut[cfg];
+    for (int k = lane; k <= kcut; k += kWave) {
       const int kr = (k == 0) ? 0 : M - k;
       const float2 u = buf[k], ur = buf[kr];
       const float ga = g1[k].x;
@@ -1100,6 +1102,8 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
       buf[k] = make_float2(v.y, v.x);
       if (kr != k) buf[kr] = make_float2(vr.y, vr.x);
     }
+    // beyond the band limit of the low-pass the product is an exact zero
+    for (int k = kcut + 1 + lane; k < M - kcut; k += kWave) buf[k] = make_float2(0.f, 0.f);
     wave_sync();
   }
 

@@ -44,6 +44,7 @@ struct LevelPlan {
   int radix[kPlanMaxPasses];
   long long tw_off;    // C32 offset of the twiddles in the constant blob
   long long g_off[2];  // C32 offset of G1[M] (followed by G2[M]) per config
+  int kcut[2];         // per config: G1[k] = G2[k] = 0 (below 1e-9 of the unit DC gain) for kcut < k < M - kcut
 };
 
 struct Plan {
@@ -304,6 +305,14 @@ inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p) {
           g2[k] = C32{(float)(a2 * cs[t]), (float)(-a2 * sn[t])};  // * exp(-2 pi i c k / M)
         }
       }
+      // band limit of the low-pass: bins whose gains are below 1e-9 (of a unit DC gain) are written as
+      // exact zeros by the spectral step without reading anything
+      int kc = 0;
+      for (int k = 0; k < M; ++k) {
+        const double mag = std::max(fabs((double)g1[k].re), sqrt((double)g2[k].re * g2[k].re + (double)g2[k].im * g2[k].im));
+        if (mag > 1e-9) kc = std::max(kc, std::min(k, M - k));
+      }
+      lp.kcut[c] = kc;
       p.consts.insert(p.consts.end(), g1.begin(), g1.end());
       p.consts.insert(p.consts.end(), g2.begin(), g2.end());
     }
