@@ -385,18 +385,29 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     }
   };
 
-  // software prefetch: the 6 rows of the NEXT group of 3 output rows are in flight while the
-  // current group is filtered (the symmetric extension keeps every prefetched address valid)
-  MarchRaw nxt[6];
+  // software prefetch: the 6 rows of the NEXT group(s) of 3 output rows are in flight while the
+  // current group is filtered (the symmetric extension keeps every prefetched address valid).
+  // uint16 planes (2 registers per row) keep TWO groups in flight: the kernel is bound by memory
+  // latency, not by registers or VALU.
+  constexpr int DEPTH = (IN_KIND == 0) ? 2 : 1;
+  MarchRaw nxt[DEPTH][6];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * i_begin + r, col);
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+      nxt[d][r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * (i_begin + 3 * d) + r, col);
   for (int i = i_begin; i < i_end; i += 3) {
     MarchRaw cur[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) cur[r] = nxt[r];
-    if (i + 3 < i_end) {
+    for (int r = 0; r < 6; ++r) cur[r] = nxt[0][r];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) nxt[r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * (i + 3) + r, col);
+    for (int d = 0; d + 1 < DEPTH; ++d)
+#pragma unroll
+      for (int r = 0; r < 6; ++r) nxt[d][r] = nxt[d + 1][r];
+    if (i + 3 * DEPTH < i_end) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+        nxt[DEPTH - 1][r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * (i + 3 * DEPTH) + r, col);
     }
     step(i, cur[0], cur[1], win[0], win[1], win[2], win[3], win[4], win[5]);
     if (i + 1 < i_end) step(i + 1, cur[2], cur[3], win[2], win[3], win[4], win[5], win[0], win[1]);
