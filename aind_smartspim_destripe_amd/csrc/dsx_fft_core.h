@@ -379,17 +379,30 @@ DSX_HD void dsx_bfly_composite(dsx_c32* v) {
 }
 
 // ---- per-butterfly pieces of a pass (used verbatim by k_rowfilter and by the host unit test) ----
-template <int R>
+// JK (odd-prime radices only): input pairs (x_j, x_{R-j}) with j > JK are known to be zero (band-limited
+// spectrum in the first pass of the inverse transform) and are neither loaded nor accumulated.
+template <int R, int JK = (R - 1) / 2>
 DSX_HD void dsx_bfly_load(const dsx_c32* buf, int b, int nb, dsx_c32* v) {
+  if constexpr (JK < (R - 1) / 2) {
+    v[0] = buf[b];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-  for (int j = 0; j < R; ++j) v[j] = buf[b + j * nb];
+    for (int j = 1; j <= JK; ++j) {
+      v[j] = buf[b + j * nb];
+      v[R - j] = buf[b + (R - j) * nb];
+    }
+  } else {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < R; ++j) v[j] = buf[b + j * nb];
+  }
 }
 
 // butterfly + twiddles + autosort scatter of butterfly b (sub-transform stride s)
 // unit_tw: last pass of a transform (s * R == M, so p == 0 and every twiddle is 1)
-template <int R>
+template <int R, int JK = (R - 1) / 2>
 DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float inv_s, dsx_c32* v,
                            bool unit_tw = false) {
   const int q = (s == 1) ? 0 : dsx_mod_s(b, s, inv_s);
@@ -402,7 +415,7 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int j = 1; j <= HP; ++j) {
+    for (int j = 1; j <= JK; ++j) {
       const dsx_c32 x = v[j], y = v[R - j];
       v[j] = dsx_add(x, y);
       v[R - j] = dsx_mul_mi(dsx_sub(x, y));  // -i (x_j - x_{R-j})
@@ -412,7 +425,7 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int j = 1; j <= HP; ++j) dc = dsx_add(dc, v[j]);
+    for (int j = 1; j <= JK; ++j) dc = dsx_add(dc, v[j]);
     buf[dst] = dc;
 #if defined(__HIPCC__)
 #pragma unroll
@@ -422,7 +435,7 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (int j = 1; j <= HP; ++j) {
+      for (int j = 1; j <= JK; ++j) {
         A = dsx_fma_s(v[j], dsx_root_cos(R, (j * k) % R), A);
         B = dsx_fma_s(v[R - j], dsx_root_sin(R, (j * k) % R), B);
       }

@@ -660,7 +660,7 @@ __device__ __forceinline__ float key_f32(unsigned k) {
   return as_f32((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-template <int R, int CPL>
+template <int R, int CPL, int JK = (R - 1) / 2>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int M, int s, float inv_s,
                                          int lane) {
   constexpr int MAXB = (CPL + R - 1) / R;
@@ -670,14 +670,14 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int M, i
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
     const int b = lane + kWave * i;
-    if (b < nb) dsx_bfly_load<R>((const dsx_c32*)buf, b, nb, v[i]);
+    if (b < nb) dsx_bfly_load<R, JK>((const dsx_c32*)buf, b, nb, v[i]);
   }
   // LDS operations of one wave execute in program order: every read above precedes the writes below
   wave_sync();
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
     const int b = lane + kWave * i;
-    if (b < nb) dsx_bfly_store<R>((dsx_c32*)buf, (const dsx_c32*)tw, b, s, inv_s, v[i], unit_tw);
+    if (b < nb) dsx_bfly_store<R, JK>((dsx_c32*)buf, (const dsx_c32*)tw, b, s, inv_s, v[i], unit_tw);
     // keep the unrolled butterflies from being interleaved: their temporaries would all be live
     // at once (215+ VGPRs at 18 values per lane) for no gain -- other waves hide the latency
     __builtin_amdgcn_sched_barrier(0);
@@ -764,6 +764,22 @@ struct StaticFft<1> {  // level 1 of a 2048-wide plane
   static __device__ __forceinline__ void run(float2* buf, const float2* tw, int lane) {
     fft_static_passes<CPL, 1026, 1, 19, 9, 6>(buf, tw, lane);
   }
+  // Inverse transform of a spectrum that vanishes for kcut < k < M - kcut: the first pass (radix 19,
+  // sources b + 54 j) only sees non-zero input pairs (j, 19 - j) for j <= (kcut + 53) / 54.
+  template <int CPL, int JK>
+  static __device__ __forceinline__ void run_first_pruned(float2* buf, const float2* tw, int lane_in) {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    fft_pass<19, CPL, JK>(buf, tw, 1026, 1, 1.0f, lane);
+    fft_static_passes<CPL, 1026, 19, 9, 6>(buf, tw, lane_in);
+  }
+  template <int CPL>
+  static __device__ __forceinline__ void run_inverse(float2* buf, const float2* tw, int lane, int kcut) {
+    const int jk = (kcut + 53) / 54;
+    if (jk <= 2) run_first_pruned<CPL, 2>(buf, tw, lane);
+    else if (jk <= 4) run_first_pruned<CPL, 4>(buf, tw, lane);
+    else run<CPL>(buf, tw, lane);
+  }
 };
 template <>
 struct StaticFft<2> {  // level 2 of a 2048-wide plane: 515 values embedded in 1071
@@ -772,6 +788,10 @@ struct StaticFft<2> {  // level 2 of a 2048-wide plane: 515 values embedded in 1
   template <int CPL>
   static __device__ __forceinline__ void run(float2* buf, const float2* tw, int lane) {
     fft_static_passes<CPL, 1071, 1, 17, 9, 7>(buf, tw, lane);
+  }
+  template <int CPL>
+  static __device__ __forceinline__ void run_inverse(float2* buf, const float2* tw, int lane, int) {
+    run<CPL>(buf, tw, lane);  // the embedded operator is not band-limited
   }
 };
 
@@ -1119,7 +1139,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   }
 
   if (!(a.ablate & 2)) {
-    if constexpr (PLAN_ > 0) StaticFft<PLAN_>::template run<CPL>(buf, s_tw, lane);
+    if constexpr (PLAN_ > 0) StaticFft<PLAN_>::template run_inverse<CPL>(buf, s_tw, lane, a.kcut[cfg]);
     else fft_run<CPL>(buf, s_tw, a, lane);
   }
 
