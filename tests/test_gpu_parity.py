@@ -195,6 +195,23 @@ def test_full_plane_2048_vs_oracle():
         _assert_close(out[k], ref, ("2048", k))
 
 
+@pytest.mark.parametrize("shape", [(300, 2048), (258, 2047), (2048, 1024), (640, 2046)])
+def test_wide_planes_vs_oracle(shape):
+    """2048-wide (and nearly so) planes of other heights: the row filter's compile-time instantiations
+    (1026 = 19*9*6 direct, 515 embedded in 1071) serve any plane whose level-1 / level-2 widths match, and
+    neighbouring widths fall back to the generic kernels."""
+    planes = np.stack([synth.synthetic_plane(k, *shape) for k in (0, 1)])
+    out, cfg = filtering.destripe_planes(
+        planes, "X_0_Y_0", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT,
+        out_dtype=np.float32, return_config=True, max_batch=2,
+    )  # fmt: skip
+    for k in range(2):
+        which, _, _, ref, _ = _oracle_plane(planes[k])
+        assert int(cfg[k]) == which
+        assert out[k].shape == ref.shape
+        _assert_close(out[k], ref, (shape, k), frac=1e-4)
+
+
 def test_uint16_output_and_cohorts():
     """uint16 result (clip + truncate) and n > max_batch (several cohorts, ragged last one)."""
     planes = synth.synthetic_bank(7, 128, 160)
