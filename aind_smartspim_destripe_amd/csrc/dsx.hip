@@ -183,17 +183,17 @@ hipError_t launch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream
 
 hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s) {
   const int cpl = (a.M + 63) / 64;
+  // slot structure of the row (full 256-value groups, 64-value tail slots) and pass list: the wide levels of
+  // 2048-, 2000- and 1800-wide planes have instantiations with all of it as compile-time constants
+  const int gf = a.w >> 8, nt = (a.w - (gf << 8) + 63) >> 6;
+  auto plan_is = [&](int m, int r0, int r1, int r2) {
+    return a.M == m && a.npass == 3 && a.radix[0] == r0 && a.radix[1] == r1 && a.radix[2] == r2;
+  };
   if (cpl <= 2) return launch_rowfilter<2>(a, npairs, nb, s);
   if (cpl <= 4) return launch_rowfilter<4>(a, npairs, nb, s);
   if (cpl <= 6) return launch_rowfilter<6>(a, npairs, nb, s);
   if (cpl <= 10) return launch_rowfilter<10>(a, npairs, nb, s);
   if (cpl <= 18) {
-    // slot structure of the row (full 256-value groups, 64-value tail slots): the shapes of a 2048-wide
-    // plane (levels 1 and 2: 1026 and 515 values) run without the per-group guards
-    const int gf = a.w >> 8, nt = (a.w - (gf << 8) + 63) >> 6;
-    auto plan_is = [&](int m, int r0, int r1, int r2) {
-      return a.M == m && a.npass == 3 && a.radix[0] == r0 && a.radix[1] == r1 && a.radix[2] == r2;
-    };
     if (gf == 4 && nt == 1 && a.K == 0) {
       if (plan_is(1026, 19, 9, 6)) return launch_rowfilter<18, 4, 1, 0, 1>(a, npairs, nb, s);
       return launch_rowfilter<18, 4, 1, 0>(a, npairs, nb, s);
@@ -202,7 +202,15 @@ hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStre
       if (plan_is(1071, 17, 9, 7)) return launch_rowfilter<18, 2, 1, 1, 2>(a, npairs, nb, s);
       return launch_rowfilter<18, 2, 1, 1>(a, npairs, nb, s);
     }
+    if (gf == 1 && nt == 4 && a.K > 0) {
+      if (plan_is(1024, 16, 8, 8)) return launch_rowfilter<18, 1, 4, 1, 5>(a, npairs, nb, s);
+      if (plan_is(960, 15, 8, 8)) return launch_rowfilter<18, 1, 4, 1, 6>(a, npairs, nb, s);
+    }
     return launch_rowfilter<18>(a, npairs, nb, s);
+  }
+  if (a.K > 0 && gf == 3) {
+    if (nt == 4 && plan_is(2048, 16, 16, 8)) return launch_rowfilter<36, 3, 4, 1, 3>(a, npairs, nb, s);
+    if (nt == 3 && plan_is(1815, 15, 11, 11)) return launch_rowfilter<36, 3, 3, 1, 4>(a, npairs, nb, s);
   }
   return launch_rowfilter<36>(a, npairs, nb, s);
 }

@@ -795,6 +795,26 @@ struct StaticFft<2> {  // level 2 of a 2048-wide plane: 515 values embedded in 1
   }
 };
 
+// Further compile-time plans: the wide levels of the production tile (1600 x 2000) and of 1800 x 1800 planes.
+#define DSX_STATIC_FFT(ID, LEN, R0, R1, R2)                                                        \
+  template <>                                                                                      \
+  struct StaticFft<ID> {                                                                           \
+    static constexpr int M = LEN;                                                                  \
+    template <int CPL>                                                                             \
+    static __device__ __forceinline__ void run(float2* buf, const float2* tw, int lane) {          \
+      fft_static_passes<CPL, LEN, 1, R0, R1, R2>(buf, tw, lane);                                   \
+    }                                                                                              \
+    template <int CPL>                                                                             \
+    static __device__ __forceinline__ void run_inverse(float2* buf, const float2* tw, int lane, int) { \
+      run<CPL>(buf, tw, lane);                                                                     \
+    }                                                                                              \
+  };
+DSX_STATIC_FFT(3, 2048, 16, 16, 8)  // 1002 values (level 1 of a 2000-wide plane) embedded in 2048
+DSX_STATIC_FFT(4, 1815, 15, 11, 11) // 902 values (level 1 of an 1800-wide plane) embedded in 1815
+DSX_STATIC_FFT(5, 1024, 16, 8, 8)   // 503 values (level 2 of a 2000-wide plane) embedded in 1024
+DSX_STATIC_FFT(6, 960, 15, 8, 8)    // 453 values (level 2 of an 1800-wide plane) embedded in 960
+#undef DSX_STATIC_FFT
+
 typedef short dsx_s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ dsx_s16x2 as_s16x2(unsigned u) {
