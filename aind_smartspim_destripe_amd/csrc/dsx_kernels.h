@@ -39,6 +39,8 @@ constexpr int kWave = 64;
   {0.03522629188570953f, 0.08544127388202666f, -0.13501102001025458f, -0.45987750211849154f,   \
    0.8068915093110925f,  -0.33267055295008263f}
 
+typedef unsigned dsx_u32x2 __attribute__((ext_vector_type(2)));
+
 struct PlaneStats {
   double sum_fg;               // sum of pixels in the foreground class (>= cut-off)
   double sum_all;              // sum of all pixels
@@ -1321,7 +1323,10 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     r.f = make_float4(0.f, 0.f, 0.f, 0.f);
     if (IN_KIND != 2 && (FAST || vec_in)) {
       const long long off = img_plane + (long long)min(gy, a.H - 1) * a.W + x0;
-      if (IN_KIND == 0) r.u = *(const uint2*)((const uint16_t*)a.img + off);
+      if (IN_KIND == 0) {
+        const dsx_u32x2 u = __builtin_nontemporal_load((const dsx_u32x2*)((const uint16_t*)a.img + off));
+        r.u = make_uint2(u.x, u.y);
+      }
       else r.f = *(const float4*)((const float*)a.img + off);
     }
     return r;
@@ -1384,7 +1389,10 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
 #pragma unroll
       for (int e = 0; e < 4; ++e) u[e] = (unsigned)fminf(r[e], 65535.f);  // float -> uint saturates below at 0
       if (vec_out) {
-        *(uint2*)((uint16_t*)a.out + o) = make_uint2(u[0] | (u[1] << 16), u[2] | (u[3] << 16));
+        dsx_u32x2 pk;
+        pk.x = u[0] | (u[1] << 16);
+        pk.y = u[2] | (u[3] << 16);
+        __builtin_nontemporal_store(pk, (dsx_u32x2*)((uint16_t*)a.out + o));  // written once, not read again here
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
