@@ -57,7 +57,7 @@ def test_engine_fails_loudly_without_gpu(lib):
         filtering.log_space_fft_filtering(np.ones((16, 16), np.float32), level=1)
 
 
-@pytest.mark.parametrize("m", [1, 2, 4, 12, 20, 36, 68, 132, 260, 515, 1026, 229, 1080, 1280, 2304])
+@pytest.mark.parametrize("m", [1, 2, 4, 12, 20, 36, 42, 63, 68, 117, 126, 132, 144, 260, 515, 567, 960, 1026, 1071, 229, 1080, 1280, 1815, 2048, 2304])
 def test_fft_core_against_naive_dft(host_check, m):
     r = host_check("fft", m)
     assert r["rel_err"] < 2e-6, r
