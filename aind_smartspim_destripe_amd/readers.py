@@ -1,60 +1,66 @@
-"""Image reading interface of the directory mode (``/root/reference/code/aind_smartspim_destripe/readers.py``).
+"""Plane readers of the directory mode: same entry points as the reference's ``readers.py``.
 
-Same names and behaviour as the reference module: ``SUPPORTED_READING_EXTENSIONS``, ``_get_extension``
-(``:16-31``), ``raw_imread`` (``:34-63``) and ``imread`` (``:66-92``).  ``tifffile`` and ``imageio`` are not
-installed here: TIFF goes through :mod:`mini_tiff`; PNG (``imageio``, ``readers.py:87-88``) is not available
+``SUPPORTED_READING_EXTENSIONS``, ``_get_extension`` (reference ``readers.py:16-31``), ``raw_imread``
+(``:34-63``) and ``imread`` (``:66-92``) keep their names, arguments and results.  ``tifffile`` and ``imageio`` are
+not installed here: TIFF goes through :mod:`mini_tiff`; PNG (``imageio``, ``readers.py:87-88``) is not available
 offline and raises ``NotImplementedError`` (SmartSPIM acquisitions are TIFF).
 """
 
-from pathlib import Path
+import os
+import struct
 from typing import Union
 
 import numpy as np
 
 from . import mini_tiff
 
-PathLike = Union[Path, str]
+PathLike = Union[os.PathLike, str]
 
 SUPPORTED_READING_EXTENSIONS = [".tif", ".tiff", ".raw", ".png"]
 
+_RAW_HEADER_BYTES = 8  # two uint32: width, height
+
 
 def _get_extension(path):
-    """File extension of ``path`` including the dot (``""`` if none)."""
-    return Path(path).suffix
+    """Extension of ``path`` with its dot, ``""`` when there is none (both ``/`` and ``\\`` separate folders)."""
+    name = str(path).replace("\\", "/").rsplit("/", 1)[-1]
+    dot = name.rfind(".")
+    return name[dot:] if dot > 0 else ""
+
+
+def _raw_geometry(header: bytes):
+    """``(width, height, pixel dtype)`` of a ``.raw`` header.
+
+    The format does not record its byte order; like the reference (``readers.py:40-56``) both readings are
+    tried and the one with the smaller width wins (right for every width below 65536).
+    """
+    if len(header) < _RAW_HEADER_BYTES:
+        raise ValueError("raw plane shorter than its header")
+    big = struct.unpack(">II", header[:_RAW_HEADER_BYTES])
+    little = struct.unpack("<II", header[:_RAW_HEADER_BYTES])
+    if little[0] < big[0]:
+        return little[0], little[1], np.dtype("<u2")
+    return big[0], big[1], np.dtype(">u2")
 
 
 def raw_imread(path):
-    """Memory-map a ``.raw`` plane: two uint32 (width, height) then uint16 pixels.
-
-    The byte order is detected as the reference does (``readers.py:40-56``): read the header both ways and
-    take the order that gives the smaller width.
-    """
-    as_uint32 = np.memmap(path, dtype=">u4", mode="r", shape=(2,))
-    width_be, height_be = as_uint32[:2]
-    del as_uint32
-    as_uint32 = np.memmap(path, dtype="<u4", mode="r", shape=(2,))
-    width_le, height_le = as_uint32[:2]
-    del as_uint32
-    if width_le < width_be:
-        width, height, dtype = width_le, height_le, "<u2"
-    else:
-        width, height, dtype = width_be, height_be, ">u2"
+    """Read-only memory map of a ``.raw`` plane, shaped ``(width, height)`` as in the reference."""
     try:
-        return np.memmap(path, dtype=dtype, mode="r", offset=8, shape=(int(width), int(height)))
-    except Exception as e:
+        with open(path, "rb") as f:
+            width, height, dtype = _raw_geometry(f.read(_RAW_HEADER_BYTES))
+        return np.memmap(path, dtype=dtype, mode="r", offset=_RAW_HEADER_BYTES, shape=(width, height))
+    except Exception:
         print("Bad path: %s" % path)
-        raise e
+        raise
+
+
+def _png_imread(path):
+    raise NotImplementedError("PNG needs imageio, which is not available in this environment")
 
 
 def imread(path: PathLike) -> np.array:
-    """Load a TIFF or RAW plane; ``None`` for an unknown extension, like the reference."""
-    path = str(path)
-    img = None
-    extension = _get_extension(path)
-    if extension == ".raw":
-        img = raw_imread(path)
-    elif extension == ".tif" or extension == ".tiff":
-        img = mini_tiff.imread(path)
-    elif extension == ".png":
-        raise NotImplementedError("PNG needs imageio, which is not available in this environment")
-    return img
+    """Plane of a ``.tif`` / ``.tiff`` / ``.raw`` file; ``None`` for any other extension, like the reference."""
+    path = os.fspath(path)
+    loaders = {".raw": raw_imread, ".tif": mini_tiff.imread, ".tiff": mini_tiff.imread, ".png": _png_imread}
+    loader = loaders.get(_get_extension(path))
+    return None if loader is None else loader(path)

@@ -107,26 +107,28 @@ def test_get_extension():  # code/tests/test_readers.py:22-30
     assert readers._get_extension("no_extension") == ""
 
 
-def test_raw_imread_endianness_mocked():  # code/tests/test_readers.py:32-66
-    with patch("numpy.memmap") as mm:
-        mm.side_effect = [np.array([300, 200], dtype=">u4"), np.array([100, 50], dtype="<u4"),
-                          np.ones((300, 200), dtype=">u2")]  # fmt: skip
-        r = readers.raw_imread("fake_path.raw")
-        assert r.shape == (300, 200) and r.dtype == np.dtype(">u2")
-    with patch("numpy.memmap") as mm:
-        mm.side_effect = [np.array([100, 50], dtype=">u4"), np.array([300, 200], dtype="<u4"),
-                          np.ones((300, 200), dtype="<u2")]  # fmt: skip
-        r = readers.raw_imread("fake_path.raw")
-        assert r.shape == (300, 200) and r.dtype == np.dtype("<u2")
-    with patch("numpy.memmap", side_effect=OSError("File not found")):
-        with pytest.raises(OSError):
-            readers.raw_imread("invalid_path.raw")
+def test_raw_imread_endianness(tmp_path):
+    """The cases of code/tests/test_readers.py:32-66 on real files: a 300 x 200 plane whose header reads as a
+    smaller width in its own byte order than in the other one; a missing file raises."""
+    for order in (">", "<"):
+        p = tmp_path / "p.raw"
+        with open(p, "wb") as f:
+            f.write(np.array([300, 200], dtype=order + "u4").tobytes())
+            f.write(np.ones((300, 200), dtype=order + "u2").tobytes())
+        r = readers.raw_imread(str(p))
+        assert r.shape == (300, 200) and r.dtype == np.dtype(order + "u2") and int(r.max()) == 1
+    assert readers._raw_geometry(np.array([100, 50], dtype="<u4").tobytes()) == (100, 50, np.dtype("<u2"))
+    with pytest.raises(OSError):
+        readers.raw_imread(str(tmp_path / "invalid_path.raw"))
+    (tmp_path / "short.raw").write_bytes(b"abc")
+    with pytest.raises(ValueError):
+        readers.raw_imread(str(tmp_path / "short.raw"))
 
 
 def test_imread_dispatch_and_real_files(tmp_path):
     with patch("aind_smartspim_destripe_amd.readers.raw_imread", return_value=np.zeros((10, 10))), patch(
         "aind_smartspim_destripe_amd.mini_tiff.imread", return_value=np.ones((10, 10))
-    ):  # code/tests/test_readers.py:68-80
+    ):  # the dispatch of code/tests/test_readers.py:68-80
         assert np.array_equal(readers.imread("image.raw"), np.zeros((10, 10)))
         assert np.array_equal(readers.imread("image.tif"), np.ones((10, 10)))
         assert np.array_equal(readers.imread(Path("image.tiff")), np.ones((10, 10)))
