@@ -5,7 +5,9 @@
 //   k_zero3  ->  k_fwd_march x L  ->  k_hist x L  ->  k_otsu  ->  k_rowfilter x L
 //   ->  k_inv_march<pyramid> x (L-1)  ->  k_inv_march<final>
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen'ed by dsx_comm_init
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -81,6 +83,14 @@ struct dsx_ctx {
   int n_streams = 4;
   hipStream_t aux[kMaxStreams] = {};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {};
+  // multi-GPU: RCCL communicator of the one collective of the path (dsx_comm_*)
+  void* rccl = nullptr;  // dlopen handle of librccl.so
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  double* d_red = nullptr;  // scratch of dsx_comm_allreduce_f64
+  // copy streams of the overlapped chunk map (dsx_memcpy_*_async): 1 = upload, 2 = download
+  hipStream_t copy_stream[2] = {};
+  hipEvent_t ev_xs = nullptr;  // cross-stream ordering (dsx_stream_wait)
 };
 
 namespace {
@@ -485,6 +495,8 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_xs, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&c->t0);
   if (e == hipSuccess) e = hipEventCreate(&c->t1);
   if (e != hipSuccess) {
@@ -500,6 +512,7 @@ void dsx_destroy(dsx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)dsx_comm_destroy(ctx);
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   free_plan_buffers(ctx);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
@@ -509,6 +522,9 @@ void dsx_destroy(dsx_ctx* ctx) {
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->copy_stream[i]) { (void)hipStreamSynchronize(ctx->copy_stream[i]); (void)hipStreamDestroy(ctx->copy_stream[i]); }
+  if (ctx->ev_xs) (void)hipEventDestroy(ctx->ev_xs);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -738,6 +754,54 @@ int dsx_memcpy_d2d(dsx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
   DSX_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return DSX_OK;
 }
+/* pinned host memory + copies on their own streams: the overlapped chunk map (zarr_destriper.py) */
+namespace {
+hipStream_t pick_stream(dsx_ctx* ctx, int id) {
+  if (id == DSX_STREAM_UPLOAD) return ctx->copy_stream[0];
+  if (id == DSX_STREAM_DOWNLOAD) return ctx->copy_stream[1];
+  return ctx->stream;
+}
+bool stream_id_ok(int id) { return id == DSX_STREAM_COMPUTE || id == DSX_STREAM_UPLOAD || id == DSX_STREAM_DOWNLOAD; }
+}  // namespace
+int dsx_malloc_host(dsx_ctx* ctx, size_t bytes, void** h_ptr) {
+  if (!ctx || !h_ptr) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  hipError_t e = hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(ctx, DSX_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  return DSX_OK;
+}
+int dsx_free_host(dsx_ctx* ctx, void* h_ptr) {
+  if (!ctx) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipHostFree(h_ptr));
+  return DSX_OK;
+}
+int dsx_memcpy_h2d_async(dsx_ctx* ctx, void* d_dst, const void* src, size_t bytes, int stream_id) {
+  if (!ctx || !stream_id_ok(stream_id)) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, pick_stream(ctx, stream_id)));
+  return DSX_OK;
+}
+int dsx_memcpy_d2h_async(dsx_ctx* ctx, void* dst, const void* d_src, size_t bytes, int stream_id) {
+  if (!ctx || !stream_id_ok(stream_id)) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, pick_stream(ctx, stream_id)));
+  return DSX_OK;
+}
+int dsx_stream_wait(dsx_ctx* ctx, int waiter, int signaller) {
+  if (!ctx || !stream_id_ok(waiter) || !stream_id_ok(signaller)) return DSX_EINVAL;
+  if (waiter == signaller) return DSX_OK;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipEventRecord(ctx->ev_xs, pick_stream(ctx, signaller)));
+  DSX_HIP(hipStreamWaitEvent(pick_stream(ctx, waiter), ctx->ev_xs, 0));
+  return DSX_OK;
+}
+int dsx_stream_sync(dsx_ctx* ctx, int stream_id) {
+  if (!ctx || !stream_id_ok(stream_id)) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipStreamSynchronize(pick_stream(ctx, stream_id)));
+  return DSX_OK;
+}
 int dsx_timer_start(dsx_ctx* ctx) {
   if (!ctx) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
@@ -895,6 +959,116 @@ int dsx_foreground_background(dsx_ctx* ctx, const void* d_img, int in_dtype, siz
   } while (0);
   (void)hipFree(d_acc);
   if (rc != DSX_OK) return fail(ctx, rc, "foreground / background statistic failed");
+  return DSX_OK;
+}
+
+
+/* ---- multi-GPU: RCCL communicator (one process per GPU) ------------------ */
+namespace {
+struct RcclApi {
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclBroadcast) broadcast = nullptr;
+  decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+};
+RcclApi g_rccl;
+
+// librccl.so is loaded on first use only: single-GPU users of the library never pay for it.
+int load_rccl(dsx_ctx* ctx) {
+  if (ctx->rccl) return DSX_OK;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return fail(ctx, DSX_EHIP, std::string("dlopen(librccl.so): ") + dlerror());
+#define DSX_SYM(field, name)                                                            \
+  g_rccl.field = (decltype(g_rccl.field))dlsym(h, name);                                \
+  if (!g_rccl.field) return fail(ctx, DSX_EHIP, std::string("librccl.so lacks ") + name)
+  DSX_SYM(get_unique_id, "ncclGetUniqueId");
+  DSX_SYM(comm_init_rank, "ncclCommInitRank");
+  DSX_SYM(comm_destroy, "ncclCommDestroy");
+  DSX_SYM(broadcast, "ncclBroadcast");
+  DSX_SYM(all_reduce, "ncclAllReduce");
+  DSX_SYM(error_string, "ncclGetErrorString");
+#undef DSX_SYM
+  ctx->rccl = h;
+  return DSX_OK;
+}
+
+#define DSX_NCCL(call)                                                                          \
+  do {                                                                                          \
+    ncclResult_t r_ = (call);                                                                   \
+    if (r_ != ncclSuccess)                                                                      \
+      return fail(ctx, DSX_ECOMM, std::string(#call) + ": " + g_rccl.error_string(r_));         \
+  } while (0)
+}  // namespace
+
+int dsx_comm_unique_id(dsx_ctx* ctx, char* id, size_t id_bytes) {
+  if (!ctx || !id) return DSX_EINVAL;
+  if (id_bytes < DSX_COMM_ID_BYTES) return fail(ctx, DSX_EINVAL, "unique id buffer too small");
+  static_assert(DSX_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+  if (int rc = load_rccl(ctx)) return rc;
+  DSX_HIP(hipSetDevice(ctx->device));
+  ncclUniqueId u;
+  DSX_NCCL(g_rccl.get_unique_id(&u));
+  memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return DSX_OK;
+}
+
+int dsx_comm_init(dsx_ctx* ctx, const char* id, size_t id_bytes, int rank, int world) {
+  if (!ctx || !id) return DSX_EINVAL;
+  if (id_bytes < DSX_COMM_ID_BYTES || world < 1 || rank < 0 || rank >= world)
+    return fail(ctx, DSX_EINVAL, "bad unique id / rank / world size");
+  if (ctx->comm) return fail(ctx, DSX_EINVAL, "communicator already initialised");
+  if (int rc = load_rccl(ctx)) return rc;
+  DSX_HIP(hipSetDevice(ctx->device));
+  ncclUniqueId u;
+  memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  DSX_NCCL(g_rccl.comm_init_rank(&ctx->comm, world, u, rank));
+  ctx->comm_rank = rank;
+  ctx->comm_world = world;
+  DSX_HIP(hipMalloc((void**)&ctx->d_red, sizeof(double) * 64));
+  return DSX_OK;
+}
+
+int dsx_comm_destroy(dsx_ctx* ctx) {
+  if (!ctx) return DSX_EINVAL;
+  if (ctx->comm) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)g_rccl.comm_destroy(ctx->comm);
+    ctx->comm = nullptr;
+  }
+  if (ctx->d_red) { (void)hipFree(ctx->d_red); ctx->d_red = nullptr; }
+  ctx->comm_rank = 0;
+  ctx->comm_world = 1;
+  return DSX_OK;
+}
+
+int dsx_comm_broadcast(dsx_ctx* ctx, void* d_buf, size_t bytes, int root) {
+  if (!ctx || (!d_buf && bytes)) return DSX_EINVAL;
+  if (!ctx->comm) return fail(ctx, DSX_ECOMM, "dsx_comm_init has not been called");
+  if (root < 0 || root >= ctx->comm_world) return fail(ctx, DSX_EINVAL, "root out of range");
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_NCCL(g_rccl.broadcast(d_buf, d_buf, bytes, ncclUint8, root, ctx->comm, ctx->stream));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  return DSX_OK;
+}
+
+int dsx_comm_allreduce_f64(dsx_ctx* ctx, double* values, int n, int op) {
+  if (!ctx || !values || n < 1 || n > 64) return DSX_EINVAL;
+  if (!ctx->comm) return fail(ctx, DSX_ECOMM, "dsx_comm_init has not been called");
+  const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
+  if (op < 0 || op > 2) return fail(ctx, DSX_EINVAL, "reduction: 0 sum, 1 max, 2 min");
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipMemcpyAsync(ctx->d_red, values, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  DSX_NCCL(g_rccl.all_reduce(ctx->d_red, ctx->d_red, n, ncclDouble, ops[op], ctx->comm, ctx->stream));
+  DSX_HIP(hipMemcpyAsync(values, ctx->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  DSX_HIP(hipStreamSynchronize(ctx->stream));
   return DSX_OK;
 }
 

@@ -489,18 +489,21 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
   s_h[tid] = 0;
   __syncthreads();
   const float denom = qmax - qmin;
-  const float step = denom / 256.0f;
   const float scale = 256.0f / denom;
-  // Bin of q = largest i with edges[i] <= q, edges[i] = i * step + qmin (numpy's estimate-then-correct
-  // rule ends there too).  The estimate (q - qmin) * scale is within 1e-4 of the exact position, so
-  // only values within 1e-3 of an integer need the comparison against the actual edges.
+  // Bin of q = largest i with edges[i] <= q (numpy's estimate-then-correct rule ends there too).
+  // The edges are numpy.linspace's of the reference's pinned NumPy 1.26.4: float32 end points are
+  // promoted to float64, edges[i] = i * ((max - min) / 256) + min in float64 (separate multiply and
+  // add), then rounded to float32.  The estimate (q - qmin) * scale is within 1e-4 of the exact
+  // position, so only values within 1e-3 of an integer need the comparison against the actual edges.
+  const double first64 = (double)qmin, step64 = ((double)qmax - (double)qmin) / 256.0;
+  auto edge = [&](int i) { return (float)__dadd_rn(__dmul_rn((double)i, step64), first64); };
   auto bin_of = [&](float q) {
     const float fi = (q - qmin) * scale;
     int idx = min((int)fi, 255);
     const float fr = fi - (float)idx;
     if (fr < 1e-3f || fr > 0.999f) {
-      const float e_lo = __fadd_rn(__fmul_rn((float)idx, step), qmin);
-      const float e_hi = (idx == 255) ? qmax : __fadd_rn(__fmul_rn((float)(idx + 1), step), qmin);
+      const float e_lo = edge(idx);
+      const float e_hi = (idx == 255) ? qmax : edge(idx + 1);
       if (q < e_lo) idx -= 1;
       else if (idx != 255 && q >= e_hi) idx += 1;
       idx = max(idx, 0);
@@ -590,17 +593,20 @@ __global__ __launch_bounds__(64) void k_otsu(OtsuArgs a) {
   if (!(q_lo < q_hi)) {
     otsu = (double)q_lo;  // all values equal: threshold_otsu returns that value
   } else {
+    // float32 bin edges exactly as k_hist builds them (numpy.linspace of NumPy 1.26.4), float32 bin
+    // centres (edges[:-1] + edges[1:]) / 2 as in skimage's threshold_otsu on a float32 image; the class
+    // statistics below are float64 (counts.astype(float))
     const double first = (double)q_lo, last = (double)q_hi;
     const double step = (last - first) / 256.0;
+    auto edge = [&](int i) { return (i == 256) ? q_hi : (float)__dadd_rn(__dmul_rn((double)i, step), first); };
+    auto centre = [&](int g) { return __fmul_rn(__fadd_rn(edge(g), edge(g + 1)), 0.5f); };
     const unsigned* h = a.hist + pl * 256;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int g = lane + 64 * i;
-      const double e0 = first + g * step;
-      const double e1 = (g == 255) ? last : first + (g + 1) * step;
       const double c = (double)h[g];
       s_cnt[g] = c;
-      s_cb[g] = c * (0.5 * (e0 + e1));
+      s_cb[g] = c * (double)centre(g);
     }
     __syncthreads();
     int best_g = 0;
@@ -621,9 +627,7 @@ __global__ __launch_bounds__(64) void k_otsu(OtsuArgs a) {
         if (var >= best) { best = var; best_g = g - 1; }  // descending scan: ties keep the lower bin
       }
     }
-    const double e0 = first + best_g * step;
-    const double e1 = (best_g == 255) ? last : first + (best_g + 1) * step;
-    otsu = 0.5 * (e0 + e1);
+    otsu = (double)centre(best_g);
   }
   if (lane == 0) {
     const double t = fmin(otsu >= 0 ? sqrt(otsu) : 0.0, (double)a.max_thr[cfg]);

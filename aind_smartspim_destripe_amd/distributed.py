@@ -7,11 +7,181 @@ rank owns a contiguous z-range aligned to the Zarr z-chunk, and the only collect
 broadcast (root 0) of the constant blob -- filter tables and, when shading is on, the flat / dark
 planes -- before the data path starts.  Nothing on the data path communicates.
 
-``torch.distributed`` is the transport (backend ``nccl`` == RCCL over xGMI for device tensors,
-``gloo`` for host tensors / CPU tests); it is passed in, this module does not import torch itself.
+Two transports:
+
+* :class:`RankGroup` -- the product path.  RCCL straight through the C ABI (``dsx_comm_*`` in
+  ``include/dsx.h``, ``librccl.so`` dlopen'ed by the engine; no torch).  The 128-byte unique id goes
+  from rank 0 to the other ranks through :class:`FileRendezvous` (one node) or any channel the
+  caller has; ``torchrun`` is only the launcher that sets ``RANK`` / ``LOCAL_RANK`` / ``WORLD_SIZE``.
+* a ``torch.distributed`` process group passed in by the caller (``broadcast_array`` & co.): ``gloo``
+  for the CPU tests of the sharding logic, ``nccl`` (== RCCL) if a host program already has one.
 """
 
+import hashlib
+import os
+import tempfile
+import time
+
 import numpy as np
+
+
+class FileRendezvous:
+    """Tiny single-node key/value rendezvous on a directory: hands the RCCL unique id from rank 0 to
+    the other ranks of ONE launch.  Files are written to a temporary name and renamed, so a reader
+    sees a key either whole or not at all.
+
+    The directory is keyed by the launcher's pid (``os.getppid()``: all ranks of a ``torchrun``
+    launch share it, consecutive launches do not) and ``MASTER_PORT``; ``DSX_RDZV_DIR`` overrides it
+    for launchers whose ranks do not share a parent.
+    """
+
+    def __init__(self, rank, world, directory=None, timeout=120.0):
+        self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        directory = directory or os.environ.get("DSX_RDZV_DIR")
+        if directory is None:
+            tag = "{}_{}".format(os.getppid(), os.environ.get("MASTER_PORT", "0"))
+            directory = os.path.join(tempfile.gettempdir(), "dsx_rdzv_" + tag)
+        self.dir = directory
+        os.makedirs(self.dir, exist_ok=True)
+
+    def _path(self, key):
+        return os.path.join(self.dir, key)
+
+    def put(self, key, data):
+        fd, tmp = tempfile.mkstemp(dir=self.dir, prefix=".tmp_")
+        with os.fdopen(fd, "wb") as f:
+            f.write(data)
+        os.replace(tmp, self._path(key))
+
+    def get(self, key):
+        t_end = time.time() + self.timeout
+        while True:
+            try:
+                with open(self._path(key), "rb") as f:
+                    return f.read()
+            except FileNotFoundError:
+                if time.time() > t_end:
+                    raise TimeoutError("rendezvous key {!r} did not appear in {}".format(key, self.dir))
+                time.sleep(0.005)
+
+    def barrier(self, name):
+        """All ranks arrive (host-side only; the data path never needs it)."""
+        self.put("{}.{}".format(name, self.rank), b"1")
+        for r in range(self.world):
+            self.get("{}.{}".format(name, r))
+
+    def cleanup(self):
+        """Rank 0, after a final barrier: remove the directory."""
+        if self.rank != 0:
+            return
+        for f in os.listdir(self.dir):
+            try:
+                os.remove(self._path(f))
+            except OSError:
+                pass
+        try:
+            os.rmdir(self.dir)
+        except OSError:
+            pass
+
+
+class RankGroup:
+    """The ranks of one job around their engines' RCCL communicator (``dsx_comm_*``).
+
+    ``RankGroup.from_env(engine)`` reads ``RANK`` / ``WORLD_SIZE`` (set by ``torchrun``); world size 1
+    needs no communicator and every collective is the identity.
+    """
+
+    def __init__(self, engine, rank, world, rendezvous=None):
+        self.engine, self.rank, self.world = engine, int(rank), int(world)
+        self.rdzv = None
+        self.bytes_broadcast = 0
+        # DSX_FORCE_COMM=1: build the communicator even for a single rank (rehearsal of the RCCL calls on a
+        # one-GPU box)
+        self.active = self.world > 1 or os.environ.get("DSX_FORCE_COMM") == "1"
+        if self.active:
+            self.rdzv = rendezvous or FileRendezvous(self.rank, self.world)
+            if self.rank == 0:
+                uid = engine.comm_unique_id()
+                self.rdzv.put("rccl_unique_id", uid)
+            else:
+                uid = self.rdzv.get("rccl_unique_id")
+            engine.comm_init(uid, self.rank, self.world)  # collective: returns once every rank has joined
+
+    @classmethod
+    def from_env(cls, engine, rendezvous=None):
+        return cls(engine, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), rendezvous)
+
+    def allreduce(self, values, op="sum"):
+        if not self.active:
+            return [float(v) for v in values]
+        return self.engine.comm_allreduce(values, op)
+
+    def barrier(self):
+        self.allreduce([0.0])
+
+    def broadcast_device(self, d_ptr, nbytes, root=0):
+        if self.active:
+            self.engine.comm_broadcast(d_ptr, nbytes, root)
+            self.bytes_broadcast += int(nbytes)
+
+    def broadcast_constants(self, root=0):
+        """RCCL broadcast of the engine's constant blob (twiddles + per-level gain tables of both configs).
+
+        Every rank plans the same blob locally, which makes the broadcast checkable: non-root ranks
+        first overwrite theirs with 0xA5 bytes, receive the root's, and the received bytes must hash to
+        what the rank planned itself.  Raises ``RuntimeError`` on a mismatch -- a job whose collective
+        does not work must not print a healthy result.  Returns the number of bytes broadcast."""
+        ptr, nbytes = self.engine.constants_device()
+        if not self.active:
+            return 0
+        stage = self.engine.alloc(nbytes)
+        try:
+            lib, ctx = self.engine._lib, self.engine._ctx
+            import ctypes
+
+            lib.dsx_memcpy_d2d(ctx, ctypes.c_void_p(stage.ptr), ctypes.c_void_p(ptr), nbytes)
+            self.engine.sync()
+            planned = hashlib.sha256(stage.download((nbytes,), np.uint8).tobytes()).hexdigest()
+            if self.rank != root:
+                stage.upload(np.full(nbytes, 0xA5, np.uint8))
+            self.broadcast_device(stage, nbytes, root)
+            got = stage.download((nbytes,), np.uint8)
+            mine_ok = hashlib.sha256(got.tobytes()).hexdigest() == planned
+            if mine_ok and self.rank != root:
+                lib.dsx_memcpy_d2d(ctx, ctypes.c_void_p(ptr), ctypes.c_void_p(stage.ptr), nbytes)
+                self.engine.sync()
+        finally:
+            stage.free()
+        # the verdict is reduced BEFORE anybody raises: a rank that left early would hang the others
+        all_ok = self.allreduce([1.0 if mine_ok else 0.0], "min")[0] == 1.0
+        if not all_ok:
+            raise RuntimeError(
+                "rank {}: the broadcast constant blob differs from the locally planned one{}".format(
+                    self.rank, "" if not mine_ok else " on another rank"))
+        return nbytes
+
+    def broadcast_shading(self, flatfield, darkfield, shape_flat, shape_dark, root=0):
+        """Rank ``root`` holds the flat / dark planes of a tile; every rank gets device copies
+        (``dsx_set_shading_device``).  Returns the two DeviceBuffers (caller frees them)."""
+        bufs = []
+        for arr, shape in ((flatfield, shape_flat), (darkfield, shape_dark)):
+            n = int(np.prod(shape)) * 4
+            d = self.engine.alloc(n)
+            if self.rank == root:
+                d.upload(np.ascontiguousarray(arr, dtype=np.float32).reshape(shape))
+            self.broadcast_device(d, n, root)
+            bufs.append(d)
+        return bufs
+
+    def close(self):
+        if self.active:
+            try:
+                self.barrier()
+            finally:
+                self.engine.comm_destroy()
+                if self.rdzv is not None:
+                    self.rdzv.cleanup()
 
 
 def z_shard(n_slices, world_size, rank, z_chunk=64):

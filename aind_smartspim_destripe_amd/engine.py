@@ -17,9 +17,12 @@ LIB_PATH = os.environ.get("DSX_LIB") or os.path.join(_HERE, "_lib", "libdsx_hip.
 DSX_U16, DSX_F32 = 0, 1
 DSX_WAVELET_DB3 = 3
 STAGE_APPROX, STAGE_DETAIL = 0, 1
-_ERRORS = {-1: "DSX_EINVAL", -2: "DSX_ENOPLAN", -3: "DSX_EHIP", -4: "DSX_ENOMEM", -5: "DSX_ELIMIT"}
+STREAM_COMPUTE, STREAM_UPLOAD, STREAM_DOWNLOAD = 0, 1, 2
+COMM_ID_BYTES = 128
+_ERRORS = {-1: "DSX_EINVAL", -2: "DSX_ENOPLAN", -3: "DSX_EHIP", -4: "DSX_ENOMEM", -5: "DSX_ELIMIT",
+           -6: "DSX_ECOMM"}  # fmt: skip
 
-# every symbol include/dsx.h declares (tests/test_cabi_symbols.py checks the list against the header)
+# every symbol include/dsx.h declares (tests/test_host_native.py checks the list against the header)
 EXPORTED_SYMBOLS = [
     "dsx_init", "dsx_destroy", "dsx_last_error", "dsx_device_count", "dsx_plan", "dsx_plan_info",
     "dsx_set_shading_device", "dsx_constants_device", "dsx_run_host", "dsx_run_device", "dsx_sync",
@@ -28,6 +31,9 @@ EXPORTED_SYMBOLS = [
     "dsx_get_stats", "dsx_get_thresholds", "dsx_get_level", "dsx_set_stop_after",
     "dsx_bricks_to_planes_u16", "dsx_planes_to_bricks_u16", "dsx_downsample2_u16",
     "dsx_flatfield_correction", "dsx_foreground_background",
+    "dsx_comm_unique_id", "dsx_comm_init", "dsx_comm_destroy", "dsx_comm_broadcast", "dsx_comm_allreduce_f64",
+    "dsx_malloc_host", "dsx_free_host", "dsx_memcpy_h2d_async", "dsx_memcpy_d2h_async",
+    "dsx_stream_wait", "dsx_stream_sync",
 ]  # fmt: skip
 
 
@@ -117,6 +123,17 @@ def load_library(path=None):
     lib.dsx_foreground_background.argtypes = [vp, vp, i32, ctypes.c_size_t, ctypes.c_float,
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), vp]  # fmt: skip
     lib.dsx_flatfield_correction.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, ctypes.c_float, vp]
+    lib.dsx_comm_unique_id.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+    lib.dsx_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, i32, i32]
+    lib.dsx_comm_destroy.argtypes = [vp]
+    lib.dsx_comm_broadcast.argtypes = [vp, vp, ctypes.c_size_t, i32]
+    lib.dsx_comm_allreduce_f64.argtypes = [vp, ctypes.POINTER(ctypes.c_double), i32, i32]
+    lib.dsx_malloc_host.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.dsx_free_host.argtypes = [vp, vp]
+    lib.dsx_memcpy_h2d_async.argtypes = [vp, vp, vp, ctypes.c_size_t, i32]
+    lib.dsx_memcpy_d2h_async.argtypes = [vp, vp, vp, ctypes.c_size_t, i32]
+    lib.dsx_stream_wait.argtypes = [vp, i32, i32]
+    lib.dsx_stream_sync.argtypes = [vp, i32]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("dsx_destroy", "dsx_last_error"):
@@ -167,6 +184,29 @@ class DeviceBuffer:
                                             ctypes.c_void_p(self.ptr + offset), out.nbytes)
         )  # fmt: skip
         return out
+
+
+class PinnedBuffer:
+    """Page-locked host memory owned by an engine (``dsx_malloc_host``): async copies need it."""
+
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        engine._check(engine._lib.dsx_malloc_host(engine._ctx, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def array(self, shape, dtype, offset=0):
+        """NumPy view of (part of) the buffer."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        assert offset + n <= self.nbytes
+        raw = (ctypes.c_char * n).from_address(self.ptr + offset)
+        return np.frombuffer(raw, dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr is not None and self.engine._ctx is not None:
+            self.engine._lib.dsx_free_host(self.engine._ctx, ctypes.c_void_p(self.ptr))
+        self.ptr = None
 
 
 def _dtype_code(dtype):
@@ -306,6 +346,55 @@ class DestripeEngine:
         p, n = ctypes.c_void_p(), ctypes.c_size_t()
         self._check(self._lib.dsx_constants_device(self._ctx, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    # -- multi-GPU: RCCL communicator (include/dsx.h, dsx_comm_*) --------------------------------
+    def comm_unique_id(self):
+        """128-byte RCCL unique id; rank 0 creates it and hands it to the other ranks (any host channel)."""
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        self._check(self._lib.dsx_comm_unique_id(self._ctx, buf, COMM_ID_BYTES))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        """Collective over all ranks of the job."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("the RCCL unique id has {} bytes".format(COMM_ID_BYTES))
+        self._check(self._lib.dsx_comm_init(self._ctx, bytes(unique_id), COMM_ID_BYTES, int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self._lib.dsx_comm_destroy(self._ctx))
+
+    def comm_broadcast(self, d_ptr, nbytes, root=0):
+        """In-place RCCL broadcast of device memory (address or DeviceBuffer) from ``root``."""
+        ptr = d_ptr.ptr if isinstance(d_ptr, DeviceBuffer) else d_ptr
+        self._check(self._lib.dsx_comm_broadcast(self._ctx, ctypes.c_void_p(ptr), int(nbytes), int(root)))
+
+    def comm_allreduce(self, values, op="sum"):
+        """All-reduce of a few host doubles over the ranks (also a barrier): op sum / max / min."""
+        v = (ctypes.c_double * len(values))(*[float(x) for x in values])
+        self._check(self._lib.dsx_comm_allreduce_f64(self._ctx, v, len(values), {"sum": 0, "max": 1, "min": 2}[op]))
+        return [float(x) for x in v]
+
+    # -- pinned staging + copy streams (overlapped chunk map) ------------------------------------
+    def alloc_host(self, nbytes):
+        return PinnedBuffer(self, nbytes)
+
+    def copy_h2d_async(self, d_buf, host_array, stream=STREAM_UPLOAD, offset=0):
+        a = host_array
+        assert a.flags["C_CONTIGUOUS"] and offset + a.nbytes <= d_buf.nbytes
+        self._check(self._lib.dsx_memcpy_h2d_async(self._ctx, ctypes.c_void_p(d_buf.ptr + offset),
+                                                   a.ctypes.data_as(ctypes.c_void_p), a.nbytes, int(stream)))  # fmt: skip
+
+    def copy_d2h_async(self, host_array, d_buf, stream=STREAM_DOWNLOAD, offset=0):
+        a = host_array
+        assert a.flags["C_CONTIGUOUS"] and offset + a.nbytes <= d_buf.nbytes
+        self._check(self._lib.dsx_memcpy_d2h_async(self._ctx, a.ctypes.data_as(ctypes.c_void_p),
+                                                   ctypes.c_void_p(d_buf.ptr + offset), a.nbytes, int(stream)))  # fmt: skip
+
+    def stream_wait(self, waiter, signaller):
+        self._check(self._lib.dsx_stream_wait(self._ctx, int(waiter), int(signaller)))
+
+    def stream_sync(self, stream):
+        self._check(self._lib.dsx_stream_sync(self._ctx, int(stream)))
 
     def profile(self, on):
         self._check(self._lib.dsx_profile_enable(self._ctx, 1 if on else 0))

@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
 """Headline benchmark: 2048 x 2048 uint16 slices/s destriped + achieved HBM GB/s (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--shape HxW] [--shading]
 
 One "step" = one pass of the hot path (filter_stripes semantics, production parameters,
-uint16 in -> uint16 out) over a batch of 256 synthetic striped 2048 x 2048 slices that is already
-resident in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU; slices shard
-embarrassingly (weak scaling, 256 slices per rank), the only collective is an RCCL broadcast of the
-filter-constant blob before the timed region.  torch is used here for the process group only
-(barrier, max-reduce of the time, that broadcast); the engine itself is the C-ABI HIP library.
+uint16 in -> uint16 out) over a batch of 256 synthetic striped slices that is already resident in
+HBM.  N > 1: launched by torch.distributed.run (the launcher only: RANK / LOCAL_RANK / WORLD_SIZE), one
+rank per GPU; slices shard embarrassingly (weak scaling, 256 slices per rank).  The only collective
+is one RCCL broadcast of the filter-constant blob before the timed region; it, the barriers and the
+max-over-ranks of the time go straight through the C ABI (dsx_comm_*, librccl.so; no torch).
+A failing collective or a result that does not verify ends the run with a non-zero exit code.
+
+After the timed region the output is VERIFIED: planes 0 and 1 against the reference's golden samples
+(tests/golden/large_stats.npz, written by the real reference), and one plane from every sub-cohort
+stream part against a single-stream re-run of the same plane (bit-identical), so every stream's output
+is tied to the reference.
 """
 
 import argparse
@@ -26,89 +32,35 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+from aind_smartspim_destripe_amd import distributed as dsx_dist  # noqa: E402
 from aind_smartspim_destripe_amd import engine as eng_mod  # noqa: E402
 from aind_smartspim_destripe_amd import synth  # noqa: E402
 
-H = W = 2048
-ALGO_BYTES_PER_SLICE = H * W * 2 * 2  # compulsory traffic: uint16 read + uint16 write
 HBM_PEAK_GBS = 8000.0
+SETTLE_SECONDS = 1.0  # untimed back-to-back steps before the warm-up: the chip reaches its steady clock
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def init_dist(n_gpus):
-    """Process group for N > 1 (RCCL for device tensors, gloo for host tensors)."""
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and "RANK" not in os.environ:
-        return None, 0, 1, 0  # plain `python bench.py`: no process group needed
-    import torch
-    import torch.distributed as dist
-
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    torch.cuda.set_device(local)
-    global _HOST_COLLECTIVES
-    try:
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
-    except Exception as e:  # pragma: no cover - environment dependent
-        log("[bench] mixed backend init failed ({}); falling back to nccl".format(e))
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-        _HOST_COLLECTIVES = False
-    return dist, rank, world, local
+def synthetic_shading(h, w):
+    """flat = 1.0 + smooth vignetting, dark = 100."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    r2 = ((yy - h / 2.0) / (h / 2.0)) ** 2 + ((xx - w / 2.0) / (w / 2.0)) ** 2
+    flat = (1.0 - 0.15 * r2).astype(np.float32)
+    dark = np.full((h, w), 100.0, dtype=np.float32)
+    return flat, dark
 
 
-_HOST_COLLECTIVES = True  # the group has a gloo side: barriers / time reduction stay off the device
-
-
-def host_all_reduce(dist, values, op=None):
-    """All-reduce of a few scalars over the ranks (gloo when the group has it, else through the device)."""
-    import torch
-
-    t = torch.tensor(values, dtype=torch.float64)
-    if not _HOST_COLLECTIVES:
-        t = t.cuda()
-    dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
-    return [float(x) for x in t.cpu()]
-
-
-def broadcast_constants(dist, engine, rank):
-    """RCCL broadcast (root 0) of the filter-constant blob: twiddles + per-level gain tables.
-
-    Every rank has already planned the same constants, so a failing collective (a node without working
-    xGMI / RCCL) is logged and does not stop the data path, which never communicates."""
-    import ctypes
-
-    import torch
-
-    ptr, nbytes = engine.constants_device()
-    try:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        lib, ctx = engine._lib, engine._ctx
-        if rank == 0:
-            lib.dsx_memcpy_d2d(ctx, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(ptr), nbytes)
-            engine.sync()
-        dist.broadcast(buf, src=0)
-        torch.cuda.synchronize()
-        if rank != 0:
-            lib.dsx_memcpy_d2d(ctx, ctypes.c_void_p(ptr), ctypes.c_void_p(buf.data_ptr()), nbytes)
-            engine.sync()
-    except Exception as e:  # pragma: no cover - needs a multi-GPU node
-        log("[bench] rank {}: constants broadcast failed ({}); using the locally planned constants".format(rank, e))
-        return 0
-    return nbytes
-
-
-def cpu_worker(first, count, start_at):
+def cpu_worker(first, count, start_at, h, w):
     """Child process of the CPU baseline: the NumPy oracle over `count` planes on one thread.  Prints
     "start end" (epoch seconds of its timed region).  Never touches the GPU."""
     from oracle import destripe_oracle as orc
 
     p = synth.synthetic_plane(0, 256, 256)
     orc.filter_stripes(p, "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT)  # warm numpy
-    planes = [synth.synthetic_plane(k % 32, H, W) for k in range(first, first + count)]
+    planes = [synth.synthetic_plane(k % 32, h, w) for k in range(first, first + count)]
     while time.time() < start_at:  # common start so that the workers really run side by side
         time.sleep(0.01)
     t0 = time.time()
@@ -118,7 +70,7 @@ def cpu_worker(first, count, start_at):
     print("{:.6f} {:.6f}".format(t0, time.time()), flush=True)
 
 
-def cpu_baseline(n_planes, procs):
+def cpu_baseline(n_planes, procs, h, w):
     """The NumPy oracle (a port of the reference algorithm) on the host cores, bounded sample: `procs`
     independent single-thread processes (the reference's execution model, zarr_destriper.py:1151-1165),
     `n_planes` planes in total.  Children are started BEFORE this process initialises the GPU."""
@@ -126,15 +78,16 @@ def cpu_baseline(n_planes, procs):
 
     procs = max(1, min(procs, n_planes))
     per = n_planes // procs
-    start_at = time.time() + 6.0 + 0.6 * per  # imports + warm-up + making the planes
+    start_at = time.time() + 8.0 + 0.5 * per * (h * w) / (2048.0 * 2048.0)  # imports + warm-up + making the planes
     kids = [
-        subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i * per), str(per), repr(start_at)],
+        subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i * per), str(per),
+                          repr(start_at), str(h), str(w)],
                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         for i in range(procs)
     ]  # fmt: skip
     spans = []
     for k in kids:
-        out, _ = k.communicate(timeout=900)
+        out, _ = k.communicate(timeout=1500)
         if k.returncode != 0:
             raise RuntimeError("cpu baseline worker failed")
         t0, t1 = map(float, out.split()[-2:])
@@ -148,49 +101,130 @@ def cpu_baseline(n_planes, procs):
         "cores": procs,
         "kind": "port",
         "per_core": round(done / busy, 4),
-        "sample": "{} synthetic 2048x2048 uint16 planes ({} per process, {} single-thread processes side by side), "
-                  "NumPy oracle filter_stripes + uint16 cast, {:.1f} s wall".format(done, per, procs, wall),
+        "sample": "{} synthetic {}x{} uint16 planes ({} per process, {} single-thread processes side by side), "
+                  "NumPy oracle filter_stripes + uint16 cast, {:.1f} s wall".format(done, h, w, per, procs, wall),
     }  # fmt: skip
+
+
+def golden_name(h, w):
+    return "s{}".format(h) if h == w else "s{}x{}".format(h, w)
+
+
+def verify(engine, stack, d_out, h, w, batch, cohort, n_streams, shading):
+    """Tie the timed configuration's output to the reference.  Returns (ok, details)."""
+    details = {}
+    ok = True
+    out01 = d_out.download((2, h, w), np.uint16)
+    gpath = os.path.join(REPO, "tests", "golden", "large_stats.npz")
+    flat = dark = None
+    if shading is not None:
+        flat, dark = shading
+    # (1) planes 0, 1 (= bank planes 0, 1) against the real reference's samples.  With shading on, the
+    # reference's float result is pushed through flatfield_correction's arithmetic first (filtering.py:399-412).
+    if os.path.exists(gpath):
+        g = np.load(gpath, allow_pickle=False)
+        name = golden_name(h, w)
+        if name + "__k0__u16__sample" in g.files:
+            rs = np.random.RandomState(7)
+            sy, sx = rs.randint(0, h, 4096), rs.randint(0, w, 4096)
+            worst, n_off = 0, 0
+            for k in (0, 1):
+                ref = g["{}__k{}__u16__sample".format(name, k)]
+                if shading is not None:
+                    d = dark[sy, sx].astype(np.float64)
+                    ref = np.where(ref > d, ref - d, 0.0) / flat[sy, sx].astype(np.float64)
+                want = np.clip(ref, 0, 65535).astype(np.uint16).astype(np.int64)
+                got = out01[k][sy, sx].astype(np.int64)
+                diff = np.abs(got - want)
+                # truncation to uint16 is discontinuous: a float32 result within 1e-4 of an integer may land
+                # one count away; a sample under a flipped mask coefficient (<= 2 of 4096) may be further off
+                n_far = int((diff > np.maximum(1, 2e-4 * want)).sum())
+                n_off += int((diff > 0).sum())
+                worst = max(worst, int(diff.max()))
+                if n_far > 2 or diff.max() > 0.05 * want.max():
+                    ok = False
+            details["golden_planes"] = [0, 1]
+            details["golden_samples_off_by_one"] = n_off
+            details["golden_worst_count_diff"] = worst
+        else:
+            details["golden_planes"] = "no golden vector for this shape"
+    # (2) one plane of every stream part, re-run alone on the main stream: must be bit-identical
+    parts = n_streams
+    nb = min(cohort, batch)
+    while parts > 1 and nb // parts < 16:
+        parts -= 1
+    per = (nb + parts - 1) // parts
+    picks = sorted({min(nb - 1, i * per + (7 * i + 3) % max(per, 1)) for i in range(parts)} | {batch - 1})
+    d_one_in = engine.alloc(2 * h * w * 2)
+    d_one_out = engine.alloc(2 * h * w * 2)
+    try:
+        for z in picks:
+            d_one_in.upload(np.ascontiguousarray(stack[[z, 1]]))
+            engine.run_device(d_one_in, np.uint16, 2, d_one_out, np.uint16, None)
+            engine.sync()
+            alone = d_one_out.download((1, h, w), np.uint16)[0]
+            timed = d_out.download((1, h, w), np.uint16, offset=z * h * w * 2)[0]
+            if not np.array_equal(alone, timed):
+                ok = False
+                details.setdefault("stream_part_mismatch", []).append(int(z))
+    finally:
+        d_one_in.free()
+        d_one_out.free()
+    details["stream_part_planes_bit_identical"] = [int(z) for z in picks]
+    details["stream_parts"] = parts
+    return ok, details
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        return cpu_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]))
-    # Only the JSON line may reach stdout: library banners (Gloo, RCCL) are written to fd 1 directly,
+        return cpu_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
+    # Only the JSON line may reach stdout: library banners (RCCL) are written to fd 1 directly,
     # so fd 1 is pointed at stderr for the duration of the run and the line goes to the saved fd.
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: about one second)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="slices per step per GPU")
+    ap.add_argument("--shape", default="2048x2048", help="plane shape HxW (BASELINE configs: 2048x2048, 1800x1800, 1600x2000)")
+    ap.add_argument("--shading", action="store_true", help="dark / flat-field correction fused into the last kernel")
     ap.add_argument("--cohort", type=int, default=int(os.environ.get("DSX_COHORT", "256")),
                     help="planes per launch chain (workspace size)")  # fmt: skip
     ap.add_argument("--cpu-planes", type=int, default=None,
-                    help="planes of the CPU baseline sample (default: 4 per process; 0 = skip)")
+                    help="planes of the CPU baseline sample (default: 16 per process; 0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=min(16, os.cpu_count() or 1),
                     help="single-thread oracle processes of the CPU baseline")
     ap.add_argument("--kernel-breakdown", action="store_true", help="one extra untimed step with per-kernel events")
+    ap.add_argument("--no-verify", action="store_true", help="skip the output verification (profiling runs)")
     args = ap.parse_args()
+    H, W = (int(x) for x in args.shape.lower().split("x"))
+    algo_bytes_per_slice = H * W * 2 * 2  # compulsory traffic: uint16 read + uint16 write (SURVEY 8(d))
 
-    # CPU baseline first: its workers are spawned, which must not happen once this process holds the GPU
-    cpu = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_planes != 0:
-        cpu = cpu_baseline(args.cpu_planes or 4 * args.cpu_procs, args.cpu_procs)
-        log("[bench] cpu baseline: {}".format(cpu))
-
-    dist, rank, world, local = init_dist(args.gpus)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("[bench] WORLD_SIZE {} != --gpus {}; using WORLD_SIZE".format(world, args.gpus))
 
+    # CPU baseline first (rank 0, N = 1): its workers are spawned, which must not happen once this process holds the GPU
+    cpu = None
+    if world == 1 and args.cpu_planes != 0:
+        cpu = cpu_baseline(args.cpu_planes or 16 * args.cpu_procs, args.cpu_procs, H, W)
+        log("[bench] cpu baseline: {}".format(cpu))
+
     engine = eng_mod.DestripeEngine(local)
+    shading = synthetic_shading(H, W) if args.shading else None
     info = engine.plan(H, W, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT,
-                       max_batch=min(args.cohort, args.batch))  # fmt: skip
-    blob_bytes = 0
-    if dist is not None:
-        blob_bytes = broadcast_constants(dist, engine, rank)
+                       max_batch=min(args.cohort, args.batch),
+                       flatfield=None if shading is None else shading[0],
+                       darkfield=None if shading is None else shading[1])  # fmt: skip
+    # N > 1: RCCL communicator + the one collective of the path; any failure raises (non-zero exit)
+    group = dsx_dist.RankGroup(engine, rank, world)
+    blob_bytes = group.broadcast_constants(root=0)
+    if world > 1:
+        log("[bench] rank {}: constants broadcast over RCCL, {} bytes, verified against the local plan".format(rank, blob_bytes))
 
     # synthetic stack: 32 unique planes, slice z = bank[z % 32] rolled by z // 32 rows
     t0 = time.perf_counter()
@@ -207,12 +241,15 @@ def main():
 
     def barrier():
         engine.sync()
-        if dist is not None:
-            import torch
+        group.barrier()
 
-            torch.cuda.synchronize()
-            host_all_reduce(dist, [0.0])  # barrier on the gloo side of the group
-
+    # settle: untimed, declared in config.settle_steps
+    settle_steps = 0
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < SETTLE_SECONDS:
+        step()
+        engine.sync()
+        settle_steps += 1
     for _ in range(args.warmup):
         step()
     barrier()
@@ -223,14 +260,15 @@ def main():
     dev_ms = engine.timer_stop()  # HIP events on the engine stream; also synchronises it
     barrier()
     wall = time.perf_counter() - t_start
+    wall, dev_ms = group.allreduce([wall, dev_ms], "max")
 
-    if dist is not None:
-        wall, dev_ms = host_all_reduce(dist, [wall, dev_ms], op=dist.ReduceOp.MAX)
-
-    # sanity on the result of the last step: config branch per plane and a checksum
     cfg = d_cfg.download((args.batch,), np.int32)
-    out_head = d_out.download((1, H, W), np.uint16)
     n_cells = int(cfg.sum())
+    n_streams = int(os.environ.get("DSX_STREAMS", "4"))
+    verified, vdetails = (None, {"skipped": True})
+    if not args.no_verify:
+        verified, vdetails = verify(engine, stack, d_out, H, W, args.batch, min(args.cohort, args.batch), n_streams, shading)
+        verified = bool(group.allreduce([1.0 if verified else 0.0], "min")[0] == 1.0)
 
     breakdown = None
     if args.kernel_breakdown and rank == 0:
@@ -245,16 +283,22 @@ def main():
         value = slices / wall
         ms_per_step = 1e3 * wall / args.steps
         dev_ms_per_step = dev_ms / args.steps
-        achieved = args.batch * ALGO_BYTES_PER_SLICE / (dev_ms_per_step * 1e-3) / 1e9
-        # HBM bytes per launch chain from the PMC counters (collected with rocprofv3 in separate
-        # passes and corrected as MI355X_MICROARCH.md prescribes; see profiles/r1_traffic.json)
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "r1_traffic.json")
-        if os.path.exists(tpath) and args.batch == 256:
-            with open(tpath) as f:
-                traffic = int(json.load(f)["hbm_bytes_per_step"])
+        achieved = args.batch * algo_bytes_per_slice / (dev_ms_per_step * 1e-3) / 1e9
+        # HBM bytes per launch chain from the PMC counters: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of
+        # tools/traffic.sh on this bench, corrected as MI355X_MICROARCH.md prescribes.  The figure is a
+        # property of a BUILD: it is reported only when the profile names this configuration, with its source.
+        traffic, traffic_source = None, None
+        for name in sorted(os.listdir(os.path.join(REPO, "profiles")), reverse=True):
+            if name.endswith("_traffic.json"):
+                with open(os.path.join(REPO, "profiles", name)) as f:
+                    t = json.load(f)
+                if t.get("planes_per_step") == args.batch and t.get("shape", "2048x2048") == "{}x{}".format(H, W) \
+                        and bool(t.get("shading", False)) == bool(args.shading):
+                    traffic = int(t["hbm_bytes_per_step"])
+                    traffic_source = "profiles/{} ({})".format(name, t.get("build", "build not recorded"))
+                    break
         result = {
-            "metric": "2048x2048 uint16 slices/s destriped",
+            "metric": "{}x{} uint16 slices/s destriped".format(H, W),
             "value": round(value, 2),
             "unit": "slices/s",
             "n_gpus": world,
@@ -266,32 +310,37 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "verified": verified,
             "config": {
-                "workload": "batch of {} x 2048x2048 uint16 slices per GPU, log-space wavelet-FFT destripe "
-                            "(filter_stripes semantics, production cells/no-cells configs, high_int 2500), "
-                            "uint16 out, inputs resident in HBM".format(args.batch),
+                "workload": "batch of {} x {}x{} uint16 slices per GPU, log-space wavelet-FFT destripe "
+                            "(filter_stripes semantics, production cells/no-cells configs, high_int 2500{}), "
+                            "uint16 out, inputs resident in HBM".format(
+                                args.batch, H, W, ", dark/flat-field correction on" if args.shading else ""),
                 "slices_per_gpu": args.batch,
                 "cohort": min(args.cohort, args.batch),
-                "sub_cohort_streams": int(os.environ.get("DSX_STREAMS", "4")),
+                "sub_cohort_streams": n_streams,
                 "levels": info.levels,
                 "fft_len": [info.fft_len[i] for i in range(info.levels)],
                 "planes_with_cells_config": n_cells,
                 "parallelism": "z-sharded x{}".format(world),
+                "rccl_ranks": world if world > 1 else 0,
                 "constants_broadcast_bytes": blob_bytes,
+                "settle_steps": settle_steps,
+                "verification": vdetails,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "destripe launch chain (k_dwt_fwd, k_hist, k_otsu, k_rowfilter, k_idwt) over one batch",
+                "kernel": "destripe launch chain (k_fwd_march, k_hist, k_otsu, k_rowfilter, k_inv_march) over one batch",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "algorithmic_bytes_per_launch": args.batch * ALGO_BYTES_PER_SLICE,
+                "traffic_source": traffic_source,
+                "algorithmic_bytes_per_launch": args.batch * algo_bytes_per_slice,
                 "device_ms_per_launch": round(dev_ms_per_step, 4),
                 "read_only_frac": round(achieved / 2 / HBM_PEAK_GBS, 5),
             },
-            "out_checksum": int(out_head.astype(np.uint64).sum()),
         }
         if breakdown is not None:
             result["kernel_ms"] = breakdown
@@ -302,10 +351,11 @@ def main():
     d_in.free()
     d_out.free()
     d_cfg.free()
+    group.close()
     engine.close()
-    if dist is not None:
-        host_all_reduce(dist, [0.0])
-        dist.destroy_process_group()
+    if verified is False:
+        log("[bench] VERIFICATION FAILED: {}".format(vdetails))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

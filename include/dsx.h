@@ -41,6 +41,7 @@ extern "C" {
 #define DSX_EHIP (-3)     /* HIP runtime error                                      */
 #define DSX_ENOMEM (-4)   /* device or host allocation failed                       */
 #define DSX_ELIMIT (-5)   /* plane exceeds an implementation limit                  */
+#define DSX_ECOMM (-6)    /* RCCL error / communicator not initialised              */
 
 /* plane element types */
 #define DSX_U16 0 /* uint16 pixels (TIFF path, destriper.py:172-200)                 */
@@ -112,6 +113,21 @@ int dsx_free(dsx_ctx* ctx, void* d_ptr);
 int dsx_memcpy_h2d(dsx_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int dsx_memcpy_d2h(dsx_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 int dsx_memcpy_d2d(dsx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+/* Pinned host staging + copies on their own streams, so that a caller can overlap the upload of
+ * block k+1 and the download of block k-1 with the kernels of block k -- the role the reference's
+ * producer / consumer queue plays on CPU cores (zarr_destriper.py:797-906, 1138-1172).
+ * stream ids: DSX_STREAM_COMPUTE is the context stream every dsx_run_device / re-tiling call uses. */
+#define DSX_STREAM_COMPUTE 0
+#define DSX_STREAM_UPLOAD 1
+#define DSX_STREAM_DOWNLOAD 2
+int dsx_malloc_host(dsx_ctx* ctx, size_t bytes, void** h_ptr);
+int dsx_free_host(dsx_ctx* ctx, void* h_ptr);
+int dsx_memcpy_h2d_async(dsx_ctx* ctx, void* d_dst, const void* src, size_t bytes, int stream_id);
+int dsx_memcpy_d2h_async(dsx_ctx* ctx, void* dst, const void* d_src, size_t bytes, int stream_id);
+/* Work submitted to `waiter` after this call starts only when everything submitted to `signaller`
+ * before it has finished (event record + stream wait; nothing blocks the host).                 */
+int dsx_stream_wait(dsx_ctx* ctx, int waiter, int signaller);
+int dsx_stream_sync(dsx_ctx* ctx, int stream_id);
 /* HIP events on the context stream: start, stop -> elapsed milliseconds. */
 int dsx_timer_start(dsx_ctx* ctx);
 int dsx_timer_stop(dsx_ctx* ctx, float* ms);
@@ -151,6 +167,24 @@ int dsx_flatfield_correction(dsx_ctx* ctx, const void* d_img, int in_dtype, int 
  * Synchronous.  Inside dsx_run_* the same statistic is fused into the first analysis kernel.      */
 int dsx_foreground_background(dsx_ctx* ctx, const void* d_img, int in_dtype, size_t n, float cutoff,
                               double* fore_mean, double* back_mean, void* d_mask);
+
+/* ---- multi-GPU: one process per GPU, z-ranges per rank, ONE collective ---- */
+/* The reference parallelises over chunks with OS processes and a queue (zarr_destriper.py:1138-1172)
+ * and never communicates between workers; planes are independent (:319-327).  Here the only exchange
+ * is a broadcast (root 0) of the constant blob / shading planes before the data path, straight on
+ * RCCL over xGMI (librccl.so is dlopen'ed by the first dsx_comm_* call; no torch).  Rank 0 creates
+ * the 128-byte unique id and hands it to the other ranks through any host channel (file, env,
+ * socket: aind_smartspim_destripe_amd/distributed.py has a file rendezvous), then every rank calls
+ * dsx_comm_init -- which is collective.  Broadcast / all-reduce run on the context stream and are
+ * synchronous; an all-reduce doubles as a barrier.                                               */
+#define DSX_COMM_ID_BYTES 128
+int dsx_comm_unique_id(dsx_ctx* ctx, char* id, size_t id_bytes);
+int dsx_comm_init(dsx_ctx* ctx, const char* id, size_t id_bytes, int rank, int world);
+int dsx_comm_destroy(dsx_ctx* ctx);
+/* In place on device memory: root's bytes replace everybody else's. */
+int dsx_comm_broadcast(dsx_ctx* ctx, void* d_buf, size_t bytes, int root);
+/* Host doubles (n <= 64) reduced over the ranks: op 0 = sum, 1 = max, 2 = min. */
+int dsx_comm_allreduce_f64(dsx_ctx* ctx, double* values, int n, int op);
 
 /* ---- parity / debug hooks (state of the LAST cohort of the last run) ----------------------- */
 /* Per plane of the last cohort: fore/back means and chosen config (filtering.py:459-462). */

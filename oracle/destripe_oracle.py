@@ -194,16 +194,26 @@ def waverec2(coeffs):
 def histogram256(q, nbins=256):
     """``numpy.histogram(q.ravel(), bins=256)`` restated (numpy 1.26.4 histograms.py:800-850).
 
-    Uniform edges ``linspace(min, max, 257)`` in the dtype of ``q``; index estimate
+    Uniform edges ``linspace(min, max, 257, dtype=q.dtype)``; index estimate
     ``((q - min) / (max - min)) * 256`` corrected by +-1 against the edges; last bin closed.
     Returns (counts int64[256], edges[257]).
+
+    The edges follow the reference's pinned NumPy 1.26.4 (``environment/Dockerfile:14-29``;
+    ``core/function_base.py:128-177``): there ``linspace`` promotes its float32 end points to
+    float64 (``asanyarray(start) * 1.0`` under value-based casting), builds
+    ``arange(257) * ((last - first) / 256) + first`` in float64 and only then rounds to the
+    dtype of ``q``.  NumPy >= 2 (NEP 50) would build them in float32 -- about one edge in five
+    then differs by an ulp -- so the rule is written out instead of calling ``np.linspace``.
     """
     a = q.ravel()
     first, last = a.min(), a.max()
     if first == last:
         first = first - 0.5
         last = last + 0.5
-    edges = np.linspace(first, last, nbins + 1, endpoint=True, dtype=a.dtype)
+    f64_first, f64_last = np.float64(first), np.float64(last)
+    edges64 = np.arange(nbins + 1, dtype=np.float64) * ((f64_last - f64_first) / nbins) + f64_first
+    edges64[-1] = f64_last
+    edges = edges64.astype(a.dtype)
     denom = last - first
     f_idx = ((a - first) / denom) * nbins
     idx = f_idx.astype(np.intp)

@@ -244,8 +244,71 @@ def make_misc():
     print("misc done")
 
 
+SWEEP_W1 = [63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 319, 320, 383, 384, 385, 511, 512, 513, 575, 767,
+            768, 769, 1001, 1023, 1024, 1025, 1026, 1027, 1151, 1152, 1153, 1500]  # fmt: skip
+SWEEP_H = 48
+SWEEP_SEEDS = 32
+
+
+def make_sweep():
+    """Hard-decision sweeps (Otsu returns a bin centre, the mask is a hard threshold), both dtype regimes:
+
+    (1) 32 seeds at 512 x 512 through filter_stripes (production parameters): per-level Otsu value,
+        threshold, mask count, 1024 sampled output pixels, plane sum, chosen config;
+    (2) 68 plane widths (level-1 row lengths around the multiples of 64 / 256, even and odd widths) at
+        48 rows through log_space_fft_filtering with both production configs: per-level Otsu value and
+        256 sampled output pixels.
+    """
+    d = {"versions": versions()}
+    rs = np.random.RandomState(7)
+    sy, sx = rs.randint(0, 512, 1024), rs.randint(0, 512, 1024)
+    for k in range(SWEEP_SEEDS):
+        img = synth.synthetic_plane(k, 512, 512)
+        for dt in ("u16", "f32"):
+            x = img if dt == "u16" else img.astype(np.float32)
+            fore, back, _ = ref.get_foreground_background_mean(x)
+            with Recorder() as rec:
+                out = ref.filter_stripes(
+                    image=x,
+                    input_tile_path="X_0_Y_0",
+                    no_cells_config=dict(synth.NO_CELLS_CONFIG),
+                    cells_config=dict(synth.CELLS_CONFIG),
+                    shadow_correction=None,
+                    microscope_high_int=synth.ZARR_PATH_HIGH_INT,
+                )
+            use_cells = bool(fore > back and fore > synth.ZARR_PATH_HIGH_INT)
+            cfg = synth.CELLS_CONFIG if use_cells else synth.NO_CELLS_CONFIG
+            thr = [min(cfg["max_threshold"], float(np.sqrt(o))) for o in rec.otsu_out]
+            key = "seed{}__{}".format(k, dt)
+            d[key + "__cfg"] = np.array([1 if use_cells else 0])
+            d[key + "__otsu"] = np.array(rec.otsu_out)  # coarse -> fine
+            d[key + "__thr"] = np.array(thr)
+            d[key + "__maskcount"] = np.array([int((np.sqrt(q) > t).sum()) for q, t in zip(rec.otsu_in, thr)])
+            d[key + "__sample"] = out[sy, sx]
+            d[key + "__sum"] = np.array([out.sum()])
+    print("sweep: seeds done")
+    cfgs = {"cells": dict(synth.CELLS_CONFIG), "nocells": dict(synth.NO_CELLS_CONFIG)}
+    for w1 in SWEEP_W1:
+        for W in (2 * w1 - 4, 2 * w1 - 5):
+            img = synth.synthetic_plane(w1 % 7, SWEEP_H, W)
+            for cname, cfg in cfgs.items():
+                for dt in ("u16", "f32"):
+                    x = img if dt == "u16" else img.astype(np.float32)
+                    out, otsu, thr, mc, _ = run_lsf(x, cfg)
+                    rs = np.random.RandomState(W)
+                    yy, xx = rs.randint(0, out.shape[0], 256), rs.randint(0, out.shape[1], 256)
+                    key = "w{}__{}__{}".format(W, cname, dt)
+                    d[key + "__otsu"] = np.array(otsu)
+                    d[key + "__sample"] = out[yy, xx]
+                    d[key + "__shape"] = np.array(out.shape)
+    d["widths"] = np.array(sorted({2 * w1 - 4 for w1 in SWEEP_W1} | {2 * w1 - 5 for w1 in SWEEP_W1}))
+    np.savez_compressed(os.path.join(GOLDEN, "sweep.npz"), **d)
+    print("sweep done")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
-    make_small()
-    make_misc()
-    make_large()
+    only = sys.argv[1:]
+    for name, fn in (("small", make_small), ("misc", make_misc), ("large", make_large), ("sweep", make_sweep)):
+        if not only or name in only:
+            fn()

@@ -45,3 +45,8 @@ def golden_large():
 @pytest.fixture(scope="session")
 def golden_misc():
     return _load("misc.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_sweep():
+    return _load("sweep.npz")

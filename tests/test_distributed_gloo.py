@@ -87,3 +87,151 @@ def test_two_rank_gloo_shard_and_broadcast():
     assert t0 == t1 == 200.0 and m0 == m1 == 2.0
     expect = sum(int(synth.synthetic_plane(z % 4, 16, 16).astype(np.uint64).sum()) * (z + 1) for z in range(200))
     assert c0 + c1 == expect
+
+
+# ---- RankGroup (RCCL through the C ABI): rendezvous + protocol, with the engine's collectives stubbed ----
+class _FakeBuf:
+    def __init__(self, eng, n):
+        self.eng, self.nbytes, self.data, self.ptr = eng, n, np.zeros(n, np.uint8), id(self)
+
+    def upload(self, a):
+        self.data[: a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+
+    def download(self, shape, dtype):
+        return self.data[: int(np.prod(shape)) * np.dtype(dtype).itemsize].view(dtype).reshape(shape).copy()
+
+    def free(self):
+        pass
+
+
+class _FakeEngine:
+    """Stands in for DestripeEngine on a machine without GPUs: the comm_* calls exchange through files in
+    the rendezvous directory, so the RankGroup protocol (id hand-off, blob poisoning + hash check,
+    min-reduce of the verdict) runs end to end in real processes."""
+
+    def __init__(self, rank, world, xdir, corrupt=False):
+        self.rank, self.world, self.xdir, self.corrupt, self.n = rank, world, xdir, corrupt, 0
+        self.blob = _FakeBuf(self, 4096)
+        self.blob.data[:] = np.arange(4096) % 251
+        self._lib, self._ctx = self, None
+
+    def comm_unique_id(self):
+        return bytes(range(128))
+
+    def comm_init(self, uid, rank, world):
+        assert uid == bytes(range(128)) and (rank, world) == (self.rank, self.world)
+
+    def comm_destroy(self):
+        pass
+
+    def constants_device(self):
+        return self.blob, self.blob.nbytes
+
+    def alloc(self, n):
+        return _FakeBuf(self, n)
+
+    def sync(self):
+        pass
+
+    def dsx_memcpy_d2d(self, ctx, dst, src, n):  # ctypes.c_void_p(buffer) is not needed for the fake
+        raise AssertionError("patched below")
+
+    def _xchg(self, tag, payload=None):
+        from aind_smartspim_destripe_amd.distributed import FileRendezvous
+
+        r = FileRendezvous(self.rank, self.world, self.xdir)
+        self.n += 1
+        if payload is not None:
+            r.put("{}{}.{}".format(tag, self.n, self.rank), payload)
+        return r
+
+    def comm_broadcast(self, buf, nbytes, root):
+        r = self._xchg("b", buf.data.tobytes() if self.rank == root else None)
+        got = np.frombuffer(r.get("b{}.{}".format(self.n, root)), np.uint8).copy()
+        if self.corrupt and self.rank != root:
+            got[7] ^= 1
+        buf.data[:nbytes] = got[:nbytes]
+
+    def comm_allreduce(self, values, op):
+        r = self._xchg("a", np.asarray(values, np.float64).tobytes())
+        allv = np.stack([np.frombuffer(r.get("a{}.{}".format(self.n, k)), np.float64) for k in range(self.world)])
+        return list({"sum": allv.sum(0), "max": allv.max(0), "min": allv.min(0)}[op])
+
+
+def _rankgroup_worker(rank, world, xdir, corrupt, q):
+    sys.path.insert(0, REPO)
+    import ctypes
+
+    from aind_smartspim_destripe_amd import distributed as dd
+
+    eng = _FakeEngine(rank, world, xdir, corrupt)
+    real_vp = ctypes.c_void_p
+    bufs = {}
+
+    def fake_vp(x):  # RankGroup wraps addresses in c_void_p; keep the buffer objects reachable by "address"
+        bufs[id(x) if not isinstance(x, int) else x] = x
+        return x
+
+    def d2d(ctx, dst, src, n):
+        d = dst if isinstance(dst, _FakeBuf) else next(b for b in (eng.blob,) if b.ptr == dst or b is dst)
+        s = src if isinstance(src, _FakeBuf) else next(b for b in (eng.blob,) if b.ptr == src or b is src)
+        d.data[:n] = s.data[:n]
+
+    eng.dsx_memcpy_d2d = d2d
+    ctypes.c_void_p = fake_vp
+    try:
+        # _FakeBuf.ptr must round-trip through the fake c_void_p: use the object itself as its address
+        eng.blob.ptr = eng.blob
+        orig_alloc = eng.alloc
+
+        def alloc(n):
+            b = orig_alloc(n)
+            b.ptr = b
+            return b
+
+        eng.alloc = alloc
+        grp = dd.RankGroup(eng, rank, world, dd.FileRendezvous(rank, world, xdir))
+        try:
+            n = grp.broadcast_constants(root=0)
+            tot = grp.allreduce([float(rank + 1)], "sum")[0]
+            q.put((rank, "ok", n, tot))
+        except RuntimeError as e:
+            q.put((rank, "error", str(e), 0.0))
+    finally:
+        ctypes.c_void_p = real_vp
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_rankgroup_protocol_three_ranks(tmp_path, corrupt):
+    """Unique-id hand-off through the file rendezvous, constants broadcast with the hash check, and the
+    verdict min-reduced over the ranks: a corrupted broadcast must raise on EVERY rank (fail loudly)."""
+    import multiprocessing as mp
+
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rankgroup_worker, args=(r, world, str(tmp_path), corrupt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if corrupt:
+        assert all(r[1] == "error" for r in res), res
+    else:
+        assert [r[1] for r in res] == ["ok"] * world and all(r[2] == 4096 and r[3] == 6.0 for r in res), res
+
+
+def test_file_rendezvous_atomic_and_timeout(tmp_path):
+    from aind_smartspim_destripe_amd.distributed import FileRendezvous
+
+    a = FileRendezvous(0, 2, str(tmp_path), timeout=0.2)
+    b = FileRendezvous(1, 2, str(tmp_path), timeout=0.2)
+    with pytest.raises(TimeoutError):
+        b.get("missing")
+    a.put("k", b"x" * 128)
+    assert b.get("k") == b"x" * 128
+    assert not [f for f in os.listdir(str(tmp_path)) if f.startswith(".tmp_")]
+    a.cleanup()
+    assert not os.path.exists(str(tmp_path)) or not os.listdir(str(tmp_path))
