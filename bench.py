@@ -198,6 +198,8 @@ def main():
                     help="single-thread oracle processes of the CPU baseline")
     ap.add_argument("--kernel-breakdown", action="store_true", help="one extra untimed step with per-kernel events")
     ap.add_argument("--no-verify", action="store_true", help="skip the output verification (profiling runs)")
+    ap.add_argument("--settle", type=float, default=SETTLE_SECONDS,
+                    help="seconds of untimed back-to-back steps before the warm-up (0 for profiler runs)")
     args = ap.parse_args()
     H, W = (int(x) for x in args.shape.lower().split("x"))
     algo_bytes_per_slice = H * W * 2 * 2  # compulsory traffic: uint16 read + uint16 write
@@ -246,7 +248,7 @@ def main():
     # settle: untimed, declared in config.settle_steps
     settle_steps = 0
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < SETTLE_SECONDS:
+    while time.perf_counter() - t_settle < args.settle:
         step()
         engine.sync()
         settle_steps += 1

@@ -320,10 +320,12 @@ def gaussian_filter(shape, sigma):
     return np.broadcast_to(g, shape).copy()
 
 
-def filter_level(ch, sigma_rows, max_threshold, stages=None):
+def filter_level(ch, sigma_rows, max_threshold, stages=None, mask_override=None):
     """Body of the per-level loop, ``filtering.py:187-217``; returns ``ch_filtered`` (float64).
 
     ``sigma_rows`` is ``s = ch.shape[0] * width_fraction`` (``filtering.py:213``).
+    ``mask_override`` (tests only): take the hard decisions ``|ch| > threshold`` from the caller instead
+    -- the parity tests use it to show that, GIVEN the same decisions, the engine agrees everywhere.
     """
     ch_sq = ch**2
     ch_power = np.sqrt(ch_sq)
@@ -331,6 +333,8 @@ def filter_level(ch, sigma_rows, max_threshold, stages=None):
     otsu_threshold_sqrt = np.sqrt(otsu)
     threshold = min(max_threshold, otsu_threshold_sqrt)
     mask = ch_power > threshold
+    if mask_override is not None:
+        mask = np.asarray(mask_override, dtype=bool)
     foreground = ch * mask
     background = ch * (1 - mask)  # int64 (1 - mask) promotes float32 -> float64 here
     med = np.median(background, axis=-1)
@@ -354,11 +358,12 @@ def filter_level(ch, sigma_rows, max_threshold, stages=None):
 
 
 def log_space_fft_filtering(
-    input_image, wavelet="db3", level=0, sigma=64, max_threshold=4, return_stages=False
+    input_image, wavelet="db3", level=0, sigma=64, max_threshold=4, return_stages=False, mask_overrides=None
 ):
     """``filtering.py:139-224`` for a 2-D plane.
 
-    Stage list (``return_stages=True``) is ordered coarse -> fine like the reference loop.
+    Stage list (``return_stages=True``) is ordered coarse -> fine like the reference loop;
+    ``mask_overrides`` (tests only, same order): see :func:`filter_level`.
     """
     if wavelet != "db3":
         raise ValueError("the oracle restates db3 only (production wavelet, run_capsule.py:374-390)")
@@ -373,9 +378,10 @@ def log_space_fft_filtering(
     width_fraction = sigma / min(input_image.shape)
     stages = [] if return_stages else None
     coeff_filtered = [approx]
-    for ch, cv, cd in detail:
+    for i, (ch, cv, cd) in enumerate(detail):
         s = ch.shape[0] * width_fraction
-        ch_filtered = filter_level(ch, s, max_threshold, stages)
+        ch_filtered = filter_level(ch, s, max_threshold, stages,
+                                   None if mask_overrides is None else mask_overrides[i])
         coeff_filtered.append((ch_filtered, cv, cd))
     img_log_filtered = waverec2(coeff_filtered)
     img_filtered = np.exp(img_log_filtered) + 1.0
