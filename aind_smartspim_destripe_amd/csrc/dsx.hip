@@ -266,7 +266,12 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   }
 
   // ---- forward transform ------------------------------------------------------------------
+  // levels 1 + 2 in one kernel when the plane allows it (aa_1 never leaves the chip)
+  static const bool no_fuse = getenv("DSX_NO_FUSE") && atoi(getenv("DSX_NO_FUSE")) != 0;
+  const bool fuse12 = !no_fuse && L >= 2 && (p.W % 4) == 0 && (p.lv[0].ldin % 4) == 0 && p.lv[0].h >= 16 &&
+                      p.lv[0].w >= 16;
   for (int l = 0; l < L; ++l) {
+    if (fuse12 && l == 1) continue;
     const dsx::LevelPlan& lp = p.lv[l];
     dsx::Fwd1Args f;
     memset(&f, 0, sizeof(f));
@@ -284,9 +289,19 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     f.fg_cutoff = ctx->fg_cutoff;
     f.nstrips = (lp.w + dsx::kMarchOut - 1) / dsx::kMarchOut;
     march_segments(nb, f.nstrips, lp.h, &f.nseg, &f.rows_per_seg);
+    if (fuse12 && l == 0) {
+      const dsx::LevelPlan& l2 = p.lv[1];
+      f.aa2_off = l2.aa_off; f.da2_off = l2.da_off;
+      f.h2 = l2.h; f.w2 = l2.w; f.ld2 = l2.ld; f.lda2 = l2.lda;
+      f.nstrips = (l2.w + dsx::kFuseOut - 1) / dsx::kFuseOut;
+      march_segments(nb, f.nstrips, l2.h, &f.nseg, &f.rows_per_seg);
+    }
     dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
     LaunchScope ls(ctx, l == 0 ? KC_FWD1 : KC_FWD);
-    if (l > 0) {
+    if (fuse12 && l == 0) {
+      if (in_dtype == DSX_U16) hipLaunchKernelGGL((dsx::k_fwd_march<0, true>), grid, dim3(256), 0, s, f);
+      else hipLaunchKernelGGL((dsx::k_fwd_march<1, true>), grid, dim3(256), 0, s, f);
+    } else if (l > 0) {
       hipLaunchKernelGGL(dsx::k_fwd_march<2>, grid, dim3(256), 0, s, f);
     } else if (in_dtype == DSX_U16) {
       hipLaunchKernelGGL(dsx::k_fwd_march<0>, grid, dim3(256), 0, s, f);

@@ -119,10 +119,18 @@ struct Fwd1Args {
   PlaneStats* stats;
   float fg_cutoff;
   int nstrips, nseg, rows_per_seg;
+  // FUSE (k_fwd_march<IN_KIND, true>): the level-2 analysis runs in the same wave, aa_1 never leaves the
+  // chip.  Strips are then counted in level-2 columns (kFuseOut per wave), segments in level-2 rows.
+  long long aa2_off, da2_off;
+  int h2, w2, ld2, lda2;
 };
 
 constexpr int kMarchCols = 256;                 // input columns per wave
 constexpr int kMarchOut = (kMarchCols - 4) / 2;  // 126 coefficient columns per wave
+constexpr int kFuseOut = (kMarchOut - 4) / 2;    // 61 level-2 columns per wave of the fused kernel
+constexpr int kRingRows = 8;                     // aa_1 rows a wave keeps in LDS (6 are needed)
+constexpr int kRingPitch = 128;                  // floats per ring row (126 columns + margin positions)
+constexpr int kX2Pitch = 136;                    // (lo, hi) pairs of the level-2 row exchange (reads run to 2*63+5)
 
 template <int IN_KIND>
 struct MarchStats {
@@ -276,8 +284,33 @@ __device__ __forceinline__ void march_consume(const Fwd1Args& a, const MarchRaw&
 // Body of k_fwd_march for one wave.  FAST: every lane's column group is vector-loadable, the loads
 // are unconditional (two instantiations instead of one: if the scalar path shared the registers of
 // the prefetch loads the compiler would drain vmcnt before every one of them).
-template <int IN_KIND, bool FAST>
+typedef float dsx_f2 __attribute__((ext_vector_type(2)));
+typedef float dsx_f4 __attribute__((ext_vector_type(4)));
+
+// Geometry of a wave of the fused kernel.  A strip produces kFuseOut level-2 columns starting at o2; the
+// LAST strip is shifted left so that it is full (it recomputes columns the strip before it owns: the
+// mirror sources of the right-hand extension are then always inside the strip).  Ownership -- who
+// stores a coefficient, who accounts a pixel in the statistic -- stays a partition:
+// strip s owns level-2 columns [61 s, ..), level-1 columns [122 s, ..), pixels [244 s, ..).
+struct FuseGeom {
+  int o2;        // first level-2 column of the wave
+  int j0;        // first level-1 column (lane 0): 2 o2 - 4, may be -4
+  int own2_lo;   // level-2 columns >= own2_lo are stored by this strip
+  int own1_lo, own1_hi;  // level-1 (da_1) columns stored by this strip
+};
+__device__ __forceinline__ FuseGeom fuse_geom(const Fwd1Args& a, int strip) {
+  FuseGeom g;
+  g.o2 = min(kFuseOut * strip, max(0, a.w2 - kFuseOut));
+  g.j0 = 2 * g.o2 - 4;
+  g.own2_lo = kFuseOut * strip;
+  g.own1_lo = 2 * kFuseOut * strip;
+  g.own1_hi = (strip == a.nstrips - 1) ? a.w : 2 * kFuseOut * (strip + 1);
+  return g;
+}
+
+template <int IN_KIND, bool FAST, bool FUSE>
 __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)[2][2][kMarchCols / 2],
+                                               float (*s_ring)[kRingRows][kRingPitch], float2 (*s_x2)[kX2Pitch],
                                                int lane, int wave, int strip, int seg, int plane,
                                                const MarchCol& col, bool any_rev) {
   constexpr float LO[6] = DSX_DEC_LO;
@@ -286,9 +319,19 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   constexpr float KS = (IN_KIND == 2) ? 1.0f : 0.69314718055994530942f;
   constexpr float LOV[6] = {LO[0] * KS, LO[1] * KS, LO[2] * KS, LO[3] * KS, LO[4] * KS, LO[5] * KS};
   constexpr float HIV[6] = {HI[0] * KS, HI[1] * KS, HI[2] * KS, HI[3] * KS, HI[4] * KS, HI[5] * KS};
-  const int i_begin = seg * a.rows_per_seg;
-  const int i_end = min(a.h, i_begin + a.rows_per_seg);
-  const int j0 = kMarchOut * strip;
+  // FUSE: the segment is counted in level-2 rows [i2b, i2e); it runs the level-1 rows those need
+  // (4 rows of overlap with the segment above, which owns them) and owns level-1 rows >= own_row_lo
+  const FuseGeom fg = FUSE ? fuse_geom(a, strip) : FuseGeom();
+  const int i2b = seg * a.rows_per_seg;
+  const int i2e = FUSE ? min(a.h2, i2b + a.rows_per_seg) : 0;
+  const int i_begin = FUSE ? max(0, 2 * i2b - 4) : seg * a.rows_per_seg;
+  const int i_end = FUSE ? min(a.h, 2 * i2e) : min(a.h, i_begin + a.rows_per_seg);
+  const int own_row_lo = FUSE ? 2 * i2b : i_begin;
+  const int j0 = FUSE ? fg.j0 : kMarchOut * strip;
+  int next2 = i2b;  // next level-2 row to emit
+  float q2min = __builtin_huge_valf(), q2max = 0.f;
+  float* aa2 = FUSE ? a.ws + plane * a.ws_plane_stride + a.aa2_off : nullptr;
+  float* da2 = FUSE ? a.ws + plane * a.ws_plane_stride + a.da2_off : nullptr;
   const void* src;
   if (IN_KIND == 0) src = (const uint16_t*)a.in + plane * a.in_plane_stride;
   else if (IN_KIND == 1) src = (const float*)a.in + plane * a.in_plane_stride;
@@ -312,13 +355,60 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   float qmin = __builtin_huge_valf(), qmax = 0.f;
   const int jj0 = 2 * lane;  // this lane's two output columns (lanes 0..62)
   const bool out_lane = lane < kMarchOut / 2;
-  const bool edge_strip = (j0 == 0) || (j0 + kMarchOut >= a.w - 8);
+  const bool edge_strip = (j0 <= 0) || (j0 + kMarchOut >= a.w - 8);
+
+  // ---- FUSE: one level-2 row from the aa_1 ring (rows 2 i2 - 4 .. 2 i2 + 1, half-sample symmetric) ----
+  auto l2_step = [&](int i2) {
+    dsx_f2 c[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      int r = 2 * i2 - 4 + k;
+      r = r < 0 ? -1 - r : (r >= a.h ? 2 * a.h - 1 - r : r);
+      c[k] = *(const dsx_f2*)&s_ring[wave][r & (kRingRows - 1)][jj0];
+    }
+    // axis 0: out = sum_k f[k] x[2 i2 + 1 - k] = sum_k f[k] c[5 - k]; both columns of the lane at once
+    dsx_f2 lo2 = LO[0] * c[5], hi2 = HI[0] * c[5];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) {
+      lo2 += LO[k] * c[5 - k];
+      hi2 += HI[k] * c[5 - k];
+    }
+    dsx_f4 pk = {lo2.x, hi2.x, lo2.y, hi2.y};  // (lo, hi) per column: the row pass filters both at once
+    *(dsx_f4*)&s_x2[wave][jj0] = pk;
+    wave_sync();
+    // axis 1, low-pass only: out[o2 + t] = sum_k LO[k] x[2 t + 5 - k] (local columns), t = lane
+    const dsx_f4 p0 = *(const dsx_f4*)&s_x2[wave][2 * lane];
+    const dsx_f4 p1 = *(const dsx_f4*)&s_x2[wave][2 * lane + 2];
+    const dsx_f4 p2 = *(const dsx_f4*)&s_x2[wave][2 * lane + 4];
+    dsx_f2 v = LO[5] * p0.xy;
+    v += LO[4] * p0.zw;
+    v += LO[3] * p1.xy;
+    v += LO[2] * p1.zw;
+    v += LO[1] * p2.xy;
+    v += LO[0] * p2.zw;
+    wave_sync();
+    const int jo = fg.o2 + lane;
+    if (lane < kFuseOut && jo < a.w2) {
+      const float q = v.y * v.y;
+      q2min = fminf(q2min, q);
+      q2max = fmaxf(q2max, q);
+      if (jo >= fg.own2_lo) {
+        float* arow = aa2 + (long long)i2 * a.lda2;
+        arow[jo] = v.x;
+        da2[(long long)i2 * a.ld2 + jo] = v.y;
+        // extension margins of aa_2, read by the next level's aligned vector loads
+        if (jo < 4) arow[-1 - jo] = v.x;
+        if (jo >= a.w2 - 8) arow[2 * a.w2 - 1 - jo] = v.x;
+      }
+    }
+  };
 
   // One output row i: the raw rows 2i, 2i+1 become window slots (r4, r5); r0..r5 = oldest..newest.
   auto step = [&](int i, const MarchRaw& raw0, const MarchRaw& raw1, float (&r0)[4], float (&r1)[4],
                   float (&r2)[4], float (&r3)[4], float (&r4)[4], float (&r5)[4]) {
-    march_consume<IN_KIND>(a, raw0, 2 * i, col, true, any_rev, st, r4);
-    march_consume<IN_KIND>(a, raw1, 2 * i + 1, col, true, any_rev, st, r5);
+    const bool own_row = !FUSE || i >= own_row_lo;  // wave-uniform
+    march_consume<IN_KIND>(a, raw0, 2 * i, col, own_row, any_rev, st, r4);
+    march_consume<IN_KIND>(a, raw1, 2 * i + 1, col, own_row, any_rev, st, r5);
     // axis 0: out = sum_k f[k] * x[2i + 1 - k] = sum_k f[k] * r(5 - k)
     float lo[4], hi[4];
 #pragma unroll
@@ -354,6 +444,47 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
       }
     }
     wave_sync();
+    if (FUSE) {
+      if (out_lane) {
+        const int j = j0 + jj0;
+        const long long o = (long long)i * a.ld + j;
+        const float q0 = res[1][0] * res[1][0], q1 = res[1][1] * res[1][1];
+        if (own_row) {  // da_1: owned rows and columns only (overlap rows / columns belong to a neighbour)
+          if (j >= fg.own1_lo && j + 1 < fg.own1_hi) {
+            *(float2*)(da + o) = make_float2(res[1][0], res[1][1]);
+          } else {
+            if (j >= fg.own1_lo && j < fg.own1_hi) da[o] = res[1][0];
+            if (j + 1 >= fg.own1_lo && j + 1 < fg.own1_hi) da[o + 1] = res[1][1];
+          }
+        }
+        if (j >= 0 && j < a.w) { qmin = fminf(qmin, q0); qmax = fmaxf(qmax, q0); }
+        if (j + 1 >= 0 && j + 1 < a.w) { qmin = fminf(qmin, q1); qmax = fmaxf(qmax, q1); }
+        // aa_1 row -> ring; edge strips also write the half-sample symmetric extension:
+        // aa[-1-k] = aa[k] (k < 4), aa[w + k] = aa[w - 1 - k] (k < 6)
+        float* ring = s_ring[wave][i & (kRingRows - 1)];
+        if (!edge_strip) {
+          *(float2*)(ring + jj0) = make_float2(res[0][0], res[0][1]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int je = j + e;
+            if (je >= 0 && je < a.w) {
+              ring[jj0 + e] = res[0][e];
+              if (je < 4 && -1 - je - j0 >= 0) ring[-1 - je - j0] = res[0][e];
+              const int t = 2 * a.w - 1 - je - j0;
+              if (je >= a.w - 6 && t < kRingPitch) ring[t] = res[0][e];
+            }
+          }
+        }
+      }
+      // level-2 rows whose six source rows are now in the ring (top rows need reflected row 3)
+      while (next2 < i2e) {
+        const int need = min(max(2 * next2 + 1, 3 - 2 * next2), a.h - 1);
+        if (need > i) break;
+        l2_step(next2);
+        ++next2;
+      }
+    } else
     if (out_lane) {
       const int j = j0 + jj0;
       const long long o = (long long)i * a.ld + j;
@@ -423,6 +554,15 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     atomicMax(&mm[0], ~as_u32(qmin));
     atomicMax(&mm[1], as_u32(qmax));
   }
+  if (FUSE) {
+    q2min = wave_min_f32(q2min);
+    q2max = wave_max_f32(q2max);
+    if (lane == 0 && q2min <= q2max) {
+      unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl + 1) * 2;
+      atomicMax(&mm[0], ~as_u32(q2min));
+      atomicMax(&mm[1], as_u32(q2max));
+    }
+  }
   if (IN_KIND != 2) {
     double s_all, s_fg;
     if (IN_KIND == 0) {
@@ -447,22 +587,44 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
 }
 
 // IN_KIND: 0 = uint16 pixels (log + statistic fused), 1 = float32 pixels (same), 2 = float32 aa_{l-1}
-template <int IN_KIND>
-__global__ __launch_bounds__(256) void k_fwd_march(Fwd1Args a) {
+// DSX_FWD_BOUNDS / DSX_INV_BOUNDS: build-time experiment hooks (tools/build_variant.sh), e.g. -DDSX_FWD_BOUNDS=256,4
+#ifndef DSX_FWD_BOUNDS
+#define DSX_FWD_BOUNDS 256
+#endif
+#ifndef DSX_INV_BOUNDS
+#define DSX_INV_BOUNDS 256
+#endif
+template <int IN_KIND, bool FUSE = false>
+__global__ __launch_bounds__(DSX_FWD_BOUNDS) void k_fwd_march(Fwd1Args a) {
   __shared__ __attribute__((aligned(16))) float s_row[4][2][2][kMarchCols / 2];  // [wave][lo|hi][parity][col/2]
+  __shared__ __attribute__((aligned(16))) float s_ring[FUSE ? 4 : 1][kRingRows][FUSE ? kRingPitch : 4];
+  __shared__ __attribute__((aligned(16))) float2 s_x2[FUSE ? 4 : 1][FUSE ? kX2Pitch : 2];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps row math on the SALU
   const int item = blockIdx.x * 4 + wave;
   if (item >= a.nstrips * a.nseg) return;
   const int strip = item % a.nstrips, seg = item / a.nstrips;
   const int plane = blockIdx.y;
-  if (seg * a.rows_per_seg >= a.h) return;
+  if (seg * a.rows_per_seg >= (FUSE ? a.h2 : a.h)) return;
+  if (FUSE) {
+    // host guarantees W % 4 == 0 and ldin % 4 == 0: every lane is vector-loadable (mirrored groups at the
+    // plane edges are aligned as well) or dead
+    const FuseGeom fg = fuse_geom(a, strip);
+    const int gc0 = 2 * fg.j0 - 4 + 4 * lane;
+    const bool owns = gc0 >= 4 * kFuseOut * strip && (strip == a.nstrips - 1 || gc0 < 4 * kFuseOut * (strip + 1));
+    MarchCol col = march_col(gc0, a.W, a.ldin, a.w, owns, false);
+    if (!col.vec) { col.dead = true; col.base = 0; col.rev = false; }  // left of the mirrored region: feeds nothing valid
+    const bool any_rev = __any(col.rev) != 0;
+    fwd_march_body<IN_KIND, true, true>(a, s_row, (float (*)[kRingRows][kRingPitch])s_ring,
+                                        (float2 (*)[kX2Pitch])s_x2, lane, wave, strip, seg, plane, col, any_rev);
+    return;
+  }
   // lane 0 re-reads the last 4 columns of the previous strip and does not account them
   const MarchCol col = march_col(2 * kMarchOut * strip - 4 + 4 * lane, a.W, a.ldin, a.w, lane >= 1, IN_KIND == 2);
   const bool all_vec = __all(col.vec || (col.dead && a.W >= 4 && (a.ldin & 3) == 0)) != 0;
   const bool any_rev = __any(col.rev) != 0;
-  if (all_vec) fwd_march_body<IN_KIND, true>(a, s_row, lane, wave, strip, seg, plane, col, any_rev);
-  else fwd_march_body<IN_KIND, false>(a, s_row, lane, wave, strip, seg, plane, col, any_rev);
+  if (all_vec) fwd_march_body<IN_KIND, true, false>(a, s_row, nullptr, nullptr, lane, wave, strip, seg, plane, col, any_rev);
+  else fwd_march_body<IN_KIND, false, false>(a, s_row, nullptr, nullptr, lane, wave, strip, seg, plane, col, any_rev);
 }
 
 // ================================================================================================
@@ -1467,7 +1629,7 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
 // IN_KIND: 0 = last level, uint16 pixels; 1 = last level, float32 pixels;
 //          2 = pyramid level: writes c_{l-1} (float32, hout x wout, pitch ldout) into the workspace
 template <int IN_KIND>
-__global__ __launch_bounds__(256) void k_inv_march(FinalArgs a) {
+__global__ __launch_bounds__(DSX_INV_BOUNDS) void k_inv_march(FinalArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps row math on the SALU
   const int item = blockIdx.x * 4 + wave;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # 4-stream throughput under row-filter ablations (diagnosis only; results are wrong with DSX_ABLATE != 0)
 for A in 0 1 2 3 7; do
-  DSX_ABLATE=$A python bench.py --cpu-planes 0 --steps 8 2>/dev/null | python -c "
+  DSX_ABLATE=$A python bench.py --cpu-planes 0 --steps 40 --warmup 5 --settle 0.3 --no-verify 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print('ablate', $A, '4-stream', d['value'], d['ms_per_step'])"
 done
