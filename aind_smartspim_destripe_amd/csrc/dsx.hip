@@ -387,7 +387,11 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   if (ctx->stop_after == 2) return DSX_OK;
 
   // ---- inverse transform of the Delta pyramid + finish ---------------------------------------
+  // level-2 synthesis inside the final kernel when the plane allows it (c_1 never leaves the chip)
+  static const bool no_fuse_inv = getenv("DSX_NO_FUSE_INV") && atoi(getenv("DSX_NO_FUSE_INV")) != 0;
+  const bool fuse21 = fuse12 && !no_fuse_inv;
   for (int l = L - 1; l >= (L > 0 ? 0 : -1); --l) {
+    if (fuse21 && l == 1) continue;
     dsx::FinalArgs f;
     memset(&f, 0, sizeof(f));
     f.ws = v.ws;
@@ -420,9 +424,24 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     }
     f.nstrips = (f.wout + dsx::kMarchCols - 1) / dsx::kMarchCols;
     march_segments(nb, f.nstrips, (f.hout + 1) / 2, &f.nseg, &f.rows_per_seg);
+    const bool fused = fuse21 && last;
+    if (fused) {
+      const dsx::LevelPlan& l2 = p.lv[1];
+      f.c2_off = l2.aa_off; f.d2_off = l2.da_off;
+      f.hc2 = l2.h; f.wc2 = l2.w; f.ldc2 = l2.lda; f.ldd2 = l2.ld;
+      f.has_c2 = (L > 2) ? 1 : 0;
+      f.has_c = 1;
+      if (f.rows_per_seg & 1) {  // segments start at even level-1 rows
+        f.rows_per_seg += 1;
+        f.nseg = ((f.hout + 1) / 2 + f.rows_per_seg - 1) / f.rows_per_seg;
+      }
+    }
     dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
     LaunchScope ls(ctx, last ? KC_FINAL : KC_INV);
-    if (!last) {
+    if (fused) {
+      if (in_dtype == DSX_U16) hipLaunchKernelGGL((dsx::k_inv_march<0, true>), grid, dim3(256), 0, s, f);
+      else hipLaunchKernelGGL((dsx::k_inv_march<1, true>), grid, dim3(256), 0, s, f);
+    } else if (!last) {
       hipLaunchKernelGGL(dsx::k_inv_march<2>, grid, dim3(256), 0, s, f);
     } else if (in_dtype == DSX_U16) {
       hipLaunchKernelGGL(dsx::k_inv_march<0>, grid, dim3(256), 0, s, f);

@@ -1386,7 +1386,12 @@ struct FinalArgs {
   float* ws_out;      // MODE 2 (pyramid level): c_{l-1} destination = ws_out + plane stride + out_off
   long long out_off;
   int ldout;
+  // FUSE (k_inv_march<IN_KIND, true>): c_1 is synthesised from level 2 inside the wave (it never touches
+  // memory): c2 / Delta_2 buffers of level 2; the c_off buffer is not read
+  long long c2_off, d2_off;
+  int hc2, wc2, ldc2, ldd2, has_c2;
 };
+constexpr int kC1Pitch = 136;  // floats per c_1 ring row: 33 lanes x 4 columns (130 are needed)
 
 struct FinalRawC {  // raw coefficients q .. q+3 of one row of c and Delta
   float2 c01, c23, d01, d23;
@@ -1439,8 +1444,9 @@ __device__ __forceinline__ float final_px(const FinalArgs& a, float c0l, float x
 // Body of k_inv_march for one wave.  FAST: every lane loads its coefficients / pixels with aligned
 // vector loads, unconditionally (row indices are clamped: rows past the end only feed result rows
 // that are never stored) -- see fwd_march_body for why this is a separate instantiation.
-template <int IN_KIND, bool FAST, bool SHADE>
-__device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int strip, int seg, int plane) {
+template <int IN_KIND, bool FAST, bool SHADE, bool FUSE = false>
+__device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int strip, int seg, int plane,
+                                               float (*s_c1)[kC1Pitch] = nullptr) {
   constexpr float RL0[6] = DSX_REC_LO;
   constexpr float RH0[6] = DSX_REC_HI;
   // last level: the result feeds exp2(), so the axis-0 taps carry the factor log2(e)
@@ -1452,6 +1458,10 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
   const int p_end = min(np, p_begin + a.rows_per_seg);
   const int x0 = kMarchCols * strip + 4 * lane;
   const int q = x0 >> 1;
+  // FUSE keeps the lanes right of the plane in the wave: their loads use a clamped (valid) address and
+  // their results are never stored
+  const int xl = FUSE ? min(x0, a.W - 4) : x0;
+  const int ql = xl >> 1;
   const float* cbase = a.ws + plane * a.ws_plane_stride + a.c_off;
   const float* dbase = a.ws + plane * a.ws_plane_stride + a.d_off;
   const bool pyr = a.has_pyr != 0;
@@ -1463,18 +1473,91 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
   const bool vec_out = ((out_pitch & 3) == 0) && ((IN_KIND == 2) ? (x0 + 3 < a.wout + 8) : (x0 + 3 < a.wout));
   const long long img_plane = plane * a.img_plane_stride;
 
+  // ---- FUSE: c_1 rows from level 2, lanes 0..32 (4 columns each), into the per-wave LDS ring ----------
+  // One step P loads level-2 row P + 2 and emits c_1 rows 2P, 2P + 1 (plain taps: c_1 is a log-image
+  // correction of level 1, the exp2 scaling only enters in the last synthesis step).
+  const int q2 = (kMarchCols / 4) * strip + 2 * lane;  // first level-2 coefficient column of the lane
+  const bool l2_lane = FUSE && lane < 33 && (kMarchCols / 2) * strip + 4 * lane < a.wc + 4;
+  const float* c2base = FUSE ? a.ws + plane * a.ws_plane_stride + a.c2_off : nullptr;
+  const float* d2base = FUSE ? a.ws + plane * a.ws_plane_stride + a.d2_off : nullptr;
+  float A2[3][4], D2[3][4];
+  FinalRawC n2;
+  int next_P = 0, c1_ready = 0;  // c_1 rows < c1_ready are in the ring
+  auto l2_load = [&](int P2) {
+    FinalRawC r;
+    r.c01 = r.c23 = r.d01 = r.d23 = make_float2(0.f, 0.f);
+    if (l2_lane) {
+      const int pr = min(P2, a.hc2 - 1);  // rows past the end only feed c_1 rows that are never used
+      if (a.has_c2) {
+        const long long rc = (long long)pr * a.ldc2 + q2;
+        r.c01 = *(const float2*)(c2base + rc);
+        r.c23 = *(const float2*)(c2base + rc + 2);
+      }
+      const long long rd = (long long)pr * a.ldd2 + q2;
+      r.d01 = *(const float2*)(d2base + rd);
+      r.d23 = *(const float2*)(d2base + rd + 2);
+    }
+    return r;
+  };
+  auto l2_step = [&](int P) {
+    final_xsynth(n2.c01, n2.c23, A2[2]);
+    final_xsynth(n2.d01, n2.d23, D2[2]);
+    n2 = l2_load(P + 3);
+    float ev[4], od[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v0 = A2[0][e] * RL0[4];
+      v0 = fmaf(A2[1][e], RL0[2], v0); v0 = fmaf(A2[2][e], RL0[0], v0);
+      v0 = fmaf(D2[0][e], RH0[4], v0); v0 = fmaf(D2[1][e], RH0[2], v0); v0 = fmaf(D2[2][e], RH0[0], v0);
+      float v1 = A2[0][e] * RL0[5];
+      v1 = fmaf(A2[1][e], RL0[3], v1); v1 = fmaf(A2[2][e], RL0[1], v1);
+      v1 = fmaf(D2[0][e], RH0[5], v1); v1 = fmaf(D2[1][e], RH0[3], v1); v1 = fmaf(D2[2][e], RH0[1], v1);
+      ev[e] = v0;
+      od[e] = v1;
+      A2[0][e] = A2[1][e]; A2[1][e] = A2[2][e];
+      D2[0][e] = D2[1][e]; D2[1][e] = D2[2][e];
+    }
+    if (lane < 33) {
+      *(float4*)&s_c1[(2 * P) & (kRingRows - 1)][4 * lane] = make_float4(ev[0], ev[1], ev[2], ev[3]);
+      *(float4*)&s_c1[(2 * P + 1) & (kRingRows - 1)][4 * lane] = make_float4(od[0], od[1], od[2], od[3]);
+    }
+    wave_sync();
+  };
+  // c_1 coefficients q .. q+3 of row p for the row synthesis (FUSE: from the ring)
+  auto ring_c = [&](int p, FinalRawC& r) {
+    while (c1_ready <= p) {  // wave-uniform
+      l2_step(next_P);
+      ++next_P;
+      c1_ready += 2;
+    }
+    const float* row = s_c1[p & (kRingRows - 1)] + 2 * lane;
+    r.c01 = *(const float2*)row;
+    r.c23 = *(const float2*)(row + 2);
+  };
+  if (FUSE) {
+    const int P0 = p_begin >> 1;  // the host makes segments start at even rows
+    next_P = P0;
+    c1_ready = 2 * P0;
+    const FinalRawC w0 = l2_load(P0), w1 = l2_load(P0 + 1);
+    final_xsynth(w0.c01, w0.c23, A2[0]);
+    final_xsynth(w0.d01, w0.d23, D2[0]);
+    final_xsynth(w1.c01, w1.c23, A2[1]);
+    final_xsynth(w1.d01, w1.d23, D2[1]);
+    n2 = l2_load(P0 + 2);
+  }
+
   auto issue_c = [&](int p) {
     FinalRawC r;
     if (FAST) {
       // rows are padded (>= 4 spare columns): coefficients past the end only feed discarded results
       const int pr = min(p, a.hc - 1);
       r.c01 = r.c23 = make_float2(0.f, 0.f);
-      if (has_c) {  // uniform: the coarsest level has no approximation correction
+      if (has_c && !FUSE) {  // uniform: the coarsest level has no approximation correction
         const long long rc = (long long)pr * a.ldc + q;
         r.c01 = *(const float2*)(cbase + rc);
         r.c23 = *(const float2*)(cbase + rc + 2);
       }
-      const long long rd = (long long)pr * a.ldd + q;
+      const long long rd = (long long)pr * a.ldd + ql;
       r.d01 = *(const float2*)(dbase + rd);
       r.d23 = *(const float2*)(dbase + rd + 2);
       return r;
@@ -1488,7 +1571,7 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     r.u = make_uint2(0u, 0u);
     r.f = make_float4(0.f, 0.f, 0.f, 0.f);
     if (IN_KIND != 2 && (FAST || vec_in)) {
-      const long long off = img_plane + (long long)min(gy, a.H - 1) * a.W + x0;
+      const long long off = img_plane + (long long)min(gy, a.H - 1) * a.W + xl;
       if (IN_KIND == 0) {
         const dsx_u32x2 u = __builtin_nontemporal_load((const dsx_u32x2*)((const uint16_t*)a.img + off));
         r.u = make_uint2(u.x, u.y);
@@ -1500,7 +1583,11 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
 
   float A[3][4], D[3][4];  // row-synthesised c and Delta rows p, p+1, p+2 (window)
   {
-    const FinalRawC r0 = issue_c(p_begin), r1 = issue_c(p_begin + 1);
+    FinalRawC r0 = issue_c(p_begin), r1 = issue_c(p_begin + 1);
+    if (FUSE) {
+      ring_c(p_begin, r0);
+      ring_c(p_begin + 1, r1);
+    }
     final_xsynth(r0.c01, r0.c23, A[0]);
     final_xsynth(r0.d01, r0.d23, D[0]);
     final_xsynth(r1.c01, r1.c23, A[1]);
@@ -1576,9 +1663,11 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
   };
 
   // one coefficient row p -> result rows 2p, 2p+1; (A0, A1, A2) = window rows p, p+1, p+2
-  auto step = [&](int p, const FinalRawC& rc, const FinalRawI<IN_KIND>& ri0, const FinalRawI<IN_KIND>& ri1,
+  auto step = [&](int p, const FinalRawC& rc_in, const FinalRawI<IN_KIND>& ri0, const FinalRawI<IN_KIND>& ri1,
                   float (&A0)[4], float (&A1)[4], float (&A2)[4], float (&D0)[4], float (&D1)[4],
                   float (&D2)[4]) {
+    FinalRawC rc = rc_in;
+    if (FUSE) ring_c(p + 2, rc);
     final_xsynth(rc.c01, rc.c23, A2);
     final_xsynth(rc.d01, rc.d23, D2);
     float even[4], odd[4];
@@ -1628,8 +1717,9 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
 
 // IN_KIND: 0 = last level, uint16 pixels; 1 = last level, float32 pixels;
 //          2 = pyramid level: writes c_{l-1} (float32, hout x wout, pitch ldout) into the workspace
-template <int IN_KIND>
+template <int IN_KIND, bool FUSE = false>
 __global__ __launch_bounds__(DSX_INV_BOUNDS) void k_inv_march(FinalArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_c1[FUSE ? 4 : 1][FUSE ? kRingRows : 1][FUSE ? kC1Pitch : 4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps row math on the SALU
   const int item = blockIdx.x * 4 + wave;
@@ -1638,6 +1728,14 @@ __global__ __launch_bounds__(DSX_INV_BOUNDS) void k_inv_march(FinalArgs a) {
   const int plane = blockIdx.y;
   if (seg * a.rows_per_seg >= ((a.hout + 1) >> 1)) return;
   const int x0 = kMarchCols * strip + 4 * lane;
+  if (FUSE) {
+    // host guarantees W % 4 == 0 and even coefficient pitches; lanes right of the plane stay in the wave
+    // (lanes 0..32 synthesise c_1 for everybody) and simply store nothing
+    float (*ring)[kC1Pitch] = (float (*)[kC1Pitch])s_c1[wave];
+    if (a.flat != nullptr) inv_march_body<IN_KIND, true, true, true>(a, lane, strip, seg, plane, ring);
+    else inv_march_body<IN_KIND, true, false, true>(a, lane, strip, seg, plane, ring);
+    return;
+  }
   if (x0 >= a.wout) return;
   // coefficient rows are padded, so every lane can load 4 coefficients; pixel rows are not
   const bool lane_fast = (a.has_pyr != 0) && ((a.ldc & 1) == 0) && ((a.ldd & 1) == 0) &&
