@@ -40,6 +40,22 @@ constexpr int kWave = 64;
    0.8068915093110925f,  -0.33267055295008263f}
 
 typedef unsigned dsx_u32x2 __attribute__((ext_vector_type(2)));
+typedef float dsx_f2 __attribute__((ext_vector_type(2)));  // arithmetic on these is packed FP32 (v_pk_fma_f32 ...)
+typedef float dsx_f4 __attribute__((ext_vector_type(4)));
+
+// Packed multiply-add with a FIXED evaluation order.  (a * b + c * d + e * f written with operators leaves
+// the choice of which product is rounded first to the compiler, and two inlined copies of one expression --
+// a segment's prologue and its steady-state loop -- did pick differently: results then depended on where
+// the row segments of a launch start, i.e. on the batch size.)
+__device__ __forceinline__ dsx_f2 pk_fma(dsx_f2 a, dsx_f2 b, dsx_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ dsx_f2 pk_fma(dsx_f2 a, float b, dsx_f2 c) {
+  const dsx_f2 bb = {b, b};
+  return __builtin_elementwise_fma(a, bb, c);
+}
+__device__ __forceinline__ dsx_f2 pk_fma(float a, dsx_f2 b, dsx_f2 c) {
+  const dsx_f2 aa = {a, a};
+  return __builtin_elementwise_fma(aa, b, c);
+}
 
 struct PlaneStats {
   double sum_fg;               // sum of pixels in the foreground class (>= cut-off)
@@ -231,6 +247,37 @@ __device__ __forceinline__ MarchRaw march_issue(const void* src, int ld, int H, 
   return r;
 }
 
+// Six consecutive raw rows g0 .. g0+5 (one prefetch group) of a FAST wave.  Interior groups -- all but the
+// first / last of a plane -- take one 64-bit row address per group and add the pitch per row, with the
+// lane's byte offset as a 32-bit vector offset on a wave-uniform base (global_load ... saddr): the row
+// index arithmetic (symmetric reflection = an integer division on the scalar unit, 64-bit multiplies)
+// was as many scalar instructions per step as the kernel has vector ones.
+template <int IN_KIND>
+__device__ __forceinline__ void march_issue6(const void* src, int ld, int H, int g0, const MarchCol& c,
+                                             MarchRaw (&out)[6]) {
+  constexpr int ES = (IN_KIND == 0) ? 2 : 4;
+  // aa_{l-1} rows carry 4 margin columns on the left (c.base >= -4): the bias keeps the lane offset unsigned
+  constexpr int BIAS = (IN_KIND == 2) ? 4 : 0;
+  const unsigned lane_off = (unsigned)(c.base + BIAS) * ES;
+  if (g0 >= 0 && g0 + 5 < H) {  // wave-uniform
+    const char* p = (const char*)src + ((long long)g0 * ld - BIAS) * ES;
+    const long long pitch = (long long)ld * ES;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const char* q = p + r * pitch;
+      if (IN_KIND == 0) {
+        const uint2 u = *(const uint2*)(q + lane_off);
+        out[r].f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+      } else {
+        out[r].f = *(const float4*)(q + lane_off);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) out[r] = march_issue<IN_KIND, true>(src, ld, H, g0 + r, c);
+  }
+}
+
 // Convert a raw row.  Pixel planes: fg/bg statistic on owned pixels, then log2(1 + x) with the bare
 // v_log_f32 (inputs are >= 1; the ln 2 factor is folded into the axis-0 filter taps).  aa_{l-1}: identity.
 template <int IN_KIND>
@@ -284,9 +331,6 @@ __device__ __forceinline__ void march_consume(const Fwd1Args& a, const MarchRaw&
 // Body of k_fwd_march for one wave.  FAST: every lane's column group is vector-loadable, the loads
 // are unconditional (two instantiations instead of one: if the scalar path shared the registers of
 // the prefetch loads the compiler would drain vmcnt before every one of them).
-typedef float dsx_f2 __attribute__((ext_vector_type(2)));
-typedef float dsx_f4 __attribute__((ext_vector_type(4)));
-
 // Geometry of a wave of the fused kernel.  A strip produces kFuseOut level-2 columns starting at o2; the
 // LAST strip is shifted left so that it is full (it recomputes columns the strip before it owns: the
 // mirror sources of the right-hand extension are then always inside the strip).  Ownership -- who
@@ -357,6 +401,20 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   const bool out_lane = lane < kMarchOut / 2;
   const bool edge_strip = (j0 <= 0) || (j0 + kMarchOut >= a.w - 8);
 
+  // FUSE: everything about a lane's columns is loop-invariant -- predicates and byte offsets are taken
+  // once, so that the row loop carries no per-iteration compares and its stores are "uniform row base +
+  // 32-bit lane offset" (no 64-bit vector address arithmetic)
+  const int jl = j0 + jj0;                                   // level-1 columns jl, jl + 1 of this lane
+  const bool c_v0 = FUSE && jl >= 0 && jl < a.w, c_v1 = FUSE && jl + 1 >= 0 && jl + 1 < a.w;
+  const bool c_s0 = FUSE && out_lane && jl >= fg.own1_lo && jl < fg.own1_hi;
+  const bool c_s1 = FUSE && out_lane && jl + 1 >= fg.own1_lo && jl + 1 < fg.own1_hi;
+  const unsigned off_da = (unsigned)max(jl, 0) * 4u;
+  const int jo2 = fg.o2 + lane;                              // level-2 column of this lane
+  const bool l2_valid = FUSE && lane < kFuseOut && jo2 < a.w2;
+  const bool l2_store = l2_valid && jo2 >= fg.own2_lo;
+  const bool l2_edge = FUSE && (fg.o2 == 0 || fg.o2 + kFuseOut >= a.w2 - 8);  // wave-uniform
+  const unsigned off_2 = (unsigned)jo2 * 4u;
+
   // ---- FUSE: one level-2 row from the aa_1 ring (rows 2 i2 - 4 .. 2 i2 + 1, half-sample symmetric) ----
   auto l2_step = [&](int i2) {
     dsx_f2 c[6];
@@ -370,8 +428,8 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     dsx_f2 lo2 = LO[0] * c[5], hi2 = HI[0] * c[5];
 #pragma unroll
     for (int k = 1; k < 6; ++k) {
-      lo2 += LO[k] * c[5 - k];
-      hi2 += HI[k] * c[5 - k];
+      lo2 = pk_fma(LO[k], c[5 - k], lo2);
+      hi2 = pk_fma(HI[k], c[5 - k], hi2);
     }
     dsx_f4 pk = {lo2.x, hi2.x, lo2.y, hi2.y};  // (lo, hi) per column: the row pass filters both at once
     *(dsx_f4*)&s_x2[wave][jj0] = pk;
@@ -381,24 +439,22 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     const dsx_f4 p1 = *(const dsx_f4*)&s_x2[wave][2 * lane + 2];
     const dsx_f4 p2 = *(const dsx_f4*)&s_x2[wave][2 * lane + 4];
     dsx_f2 v = LO[5] * p0.xy;
-    v += LO[4] * p0.zw;
-    v += LO[3] * p1.xy;
-    v += LO[2] * p1.zw;
-    v += LO[1] * p2.xy;
-    v += LO[0] * p2.zw;
+    v = pk_fma(LO[4], p0.zw, v);
+    v = pk_fma(LO[3], p1.xy, v);
+    v = pk_fma(LO[2], p1.zw, v);
+    v = pk_fma(LO[1], p2.xy, v);
+    v = pk_fma(LO[0], p2.zw, v);
     wave_sync();
-    const int jo = fg.o2 + lane;
-    if (lane < kFuseOut && jo < a.w2) {
-      const float q = v.y * v.y;
-      q2min = fminf(q2min, q);
-      q2max = fmaxf(q2max, q);
-      if (jo >= fg.own2_lo) {
-        float* arow = aa2 + (long long)i2 * a.lda2;
-        arow[jo] = v.x;
-        da2[(long long)i2 * a.ld2 + jo] = v.y;
-        // extension margins of aa_2, read by the next level's aligned vector loads
-        if (jo < 4) arow[-1 - jo] = v.x;
-        if (jo >= a.w2 - 8) arow[2 * a.w2 - 1 - jo] = v.x;
+    const float q = v.y * v.y;
+    q2min = fminf(q2min, l2_valid ? q : __builtin_huge_valf());
+    q2max = fmaxf(q2max, l2_valid ? q : 0.f);
+    if (l2_store) {
+      char* arow = (char*)(aa2 + (long long)i2 * a.lda2);
+      *(float*)(arow + off_2) = v.x;
+      *(float*)((char*)(da2 + (long long)i2 * a.ld2) + off_2) = v.y;
+      if (l2_edge) {  // extension margins of aa_2, read by the next level's aligned vector loads
+        if (jo2 < 4) ((float*)arow)[-1 - jo2] = v.x;
+        if (jo2 >= a.w2 - 8) ((float*)arow)[2 * a.w2 - 1 - jo2] = v.x;
       }
     }
   };
@@ -446,19 +502,19 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     wave_sync();
     if (FUSE) {
       if (out_lane) {
-        const int j = j0 + jj0;
-        const long long o = (long long)i * a.ld + j;
+        const int j = jl;
         const float q0 = res[1][0] * res[1][0], q1 = res[1][1] * res[1][1];
         if (own_row) {  // da_1: owned rows and columns only (overlap rows / columns belong to a neighbour)
-          if (j >= fg.own1_lo && j + 1 < fg.own1_hi) {
-            *(float2*)(da + o) = make_float2(res[1][0], res[1][1]);
+          char* drow = (char*)(da + (long long)i * a.ld);
+          if (c_s0 && c_s1) {
+            *(float2*)(drow + off_da) = make_float2(res[1][0], res[1][1]);
           } else {
-            if (j >= fg.own1_lo && j < fg.own1_hi) da[o] = res[1][0];
-            if (j + 1 >= fg.own1_lo && j + 1 < fg.own1_hi) da[o + 1] = res[1][1];
+            if (c_s0) *(float*)(drow + off_da) = res[1][0];
+            if (c_s1) *(float*)(drow + off_da + 4) = res[1][1];
           }
         }
-        if (j >= 0 && j < a.w) { qmin = fminf(qmin, q0); qmax = fmaxf(qmax, q0); }
-        if (j + 1 >= 0 && j + 1 < a.w) { qmin = fminf(qmin, q1); qmax = fmaxf(qmax, q1); }
+        qmin = fminf(qmin, fminf(c_v0 ? q0 : __builtin_huge_valf(), c_v1 ? q1 : __builtin_huge_valf()));
+        qmax = fmaxf(qmax, fmaxf(c_v0 ? q0 : 0.f, c_v1 ? q1 : 0.f));
         // aa_1 row -> ring; edge strips also write the half-sample symmetric extension:
         // aa[-1-k] = aa[k] (k < 4), aa[w + k] = aa[w - 1 - k] (k < 6)
         float* ring = s_ring[wave][i & (kRingRows - 1)];
@@ -525,10 +581,15 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   constexpr int DEPTH = (IN_KIND == 0) ? 2 : 1;
   MarchRaw nxt[DEPTH][6];
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d)
+  for (int d = 0; d < DEPTH; ++d) {
+    if (FAST) {
+      march_issue6<IN_KIND>(src, a.ldin, a.H, 2 * (i_begin + 3 * d), col, nxt[d]);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
-      nxt[d][r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * (i_begin + 3 * d) + r, col);
+      for (int r = 0; r < 6; ++r)
+        nxt[d][r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * (i_begin + 3 * d) + r, col);
+    }
+  }
   for (int i = i_begin; i < i_end; i += 3) {
     MarchRaw cur[6];
 #pragma unroll
@@ -538,9 +599,13 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
 #pragma unroll
       for (int r = 0; r < 6; ++r) nxt[d][r] = nxt[d + 1][r];
     if (i + 3 * DEPTH < i_end) {
+      if (FAST) {
+        march_issue6<IN_KIND>(src, a.ldin, a.H, 2 * (i + 3 * DEPTH), col, nxt[DEPTH - 1]);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
-        nxt[DEPTH - 1][r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * (i + 3 * DEPTH) + r, col);
+        for (int r = 0; r < 6; ++r)
+          nxt[DEPTH - 1][r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * (i + 3 * DEPTH) + r, col);
+      }
     }
     step(i, cur[0], cur[1], win[0], win[1], win[2], win[3], win[4], win[5]);
     if (i + 1 < i_end) step(i + 1, cur[2], cur[3], win[2], win[3], win[4], win[5], win[0], win[1]);
@@ -686,16 +751,33 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
   const float* da = a.ws + plane * a.ws_plane_stride + a.da_off;
   const int r0 = blockIdx.x * a.rows_per_block;
   const int r1 = min(a.h, r0 + a.rows_per_block);
-  for (int r = r0 + wave; r < r1; r += 4) {
-    const float* row = da + (long long)r * a.ld;  // 16-byte aligned, pitch a multiple of 4
-    for (int c = 4 * lane; c < a.w; c += 4 * 64) {
-      const float4 v = *(const float4*)(row + c);
+  // The kernel waits on memory, not on arithmetic: two rows x two 256-column chunks = four independent
+  // 16-byte loads are in flight per lane before the first value is binned (clamped addresses keep the
+  // loads unconditional; what a clamped load returns is not counted).
+  auto tally = [&](const float4& v, int c, bool on) {
+    if (on) {
       count(bin_of(v.x * v.x));
       if (c + 1 < a.w) count(bin_of(v.y * v.y));
       if (c + 2 < a.w) count(bin_of(v.z * v.z));
       if (c + 3 < a.w) count(bin_of(v.w * v.w));
       since_flush += 4;
-      if (since_flush >= 252) flush();
+    }
+  };
+  for (int r = r0 + wave; r < r1; r += 8) {
+    const bool two = r + 4 < r1;  // wave-uniform
+    const float* rowa = da + (long long)r * a.ld;  // 16-byte aligned, pitch a multiple of 4
+    const float* rowb = da + (long long)(two ? r + 4 : r) * a.ld;
+    for (int c = 4 * lane; c < a.w; c += 8 * 64) {
+      const int c2 = c + 4 * 64;
+      const bool on2 = c2 < a.w;
+      const int c2l = on2 ? c2 : c;
+      const float4 va0 = *(const float4*)(rowa + c), va1 = *(const float4*)(rowa + c2l);
+      const float4 vb0 = *(const float4*)(rowb + c), vb1 = *(const float4*)(rowb + c2l);
+      tally(va0, c, true);
+      tally(va1, c2, on2);
+      tally(vb0, c, two);
+      tally(vb1, c2, two && on2);
+      if (since_flush >= 236) flush();
     }
   }
   flush();
@@ -747,10 +829,12 @@ __global__ __launch_bounds__(64) void k_otsu(OtsuArgs a) {
   const long long pl = (long long)plane * a.L + lvl;
   const unsigned* mm = a.minmax + pl * 2;
   const float q_lo = as_f32(~mm[0]), q_hi = as_f32(mm[1]);
-  // The class statistics are accumulated sequentially in numpy's order (cumsum forward for
-  // class 1, cumsum over the reversed arrays for class 2): empty bins then give bit-identical
-  // variances on both sides, and "first maximum" picks the same bin as np.argmax.
-  __shared__ double s_cnt[256], s_cb[256], s_w1[256], s_m1[256];
+  // The class statistics are accumulated sequentially in numpy's order (cumsum forward for class 1,
+  // cumsum over the reversed arrays for class 2): empty bins then give bit-identical variances on both
+  // sides, and "first maximum" picks the same bin as np.argmax.  Only the two running sums are
+  // sequential (lane 0 forward, lane 1 backward, additions only); products, quotients, variances and
+  // the arg-max run on all lanes.
+  __shared__ double s_cnt[256], s_cb[256], s_w[2][256], s_s[2][256];
   double otsu;
   if (!(q_lo < q_hi)) {
     otsu = (double)q_lo;  // all values equal: threshold_otsu returns that value
@@ -771,23 +855,35 @@ __global__ __launch_bounds__(64) void k_otsu(OtsuArgs a) {
       s_cb[g] = c * (double)centre(g);
     }
     __syncthreads();
-    int best_g = 0;
-    if (lane == 0) {
+    if (lane < 2) {
       double w = 0.0, sacc = 0.0;
-      for (int g = 0; g < 256; ++g) {
+#pragma unroll 8
+      for (int k = 0; k < 256; ++k) {
+        const int g = lane ? 255 - k : k;
         w += s_cnt[g];
         sacc += s_cb[g];
-        s_w1[g] = w;
-        s_m1[g] = sacc / w;
+        s_w[lane][g] = w;
+        s_s[lane][g] = sacc;
       }
-      double w2 = 0.0, s2 = 0.0, best = -1.0;
-      for (int g = 255; g >= 1; --g) {
-        w2 += s_cnt[g];
-        s2 += s_cb[g];
-        const double d = s_m1[g - 1] - s2 / w2;
-        const double var = (s_w1[g - 1] * w2) * (d * d);  // variance12[g - 1]
-        if (var >= best) { best = var; best_g = g - 1; }  // descending scan: ties keep the lower bin
+    }
+    __syncthreads();
+    // variance12[g] = weight1[g] weight2[g + 1] (mean1[g] - mean2[g + 1])^2, g = 0 .. 254; first maximum
+    double best = -1.0;
+    int best_g = 0;
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+      const int g = lane + 64 * i;
+      if (g < 255) {
+        const double d = s_s[0][g] / s_w[0][g] - s_s[1][g + 1] / s_w[1][g + 1];
+        const double var = (s_w[0][g] * s_w[1][g + 1]) * (d * d);
+        if (var >= best) { best = var; best_g = g; }  // descending g: ties keep the lower bin
       }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o);
+      const int og = __shfl_xor(best_g, o);
+      if (ob > best || (ob == best && og < best_g)) { best = ob; best_g = og; }
     }
     otsu = (double)centre(best_g);
   }
@@ -1420,13 +1516,23 @@ __device__ __forceinline__ void final_coeff_row(const FinalArgs& a, const float*
 }
 
 // row synthesis of 4 result columns x = 4t .. 4t+3 from coefficients q .. q+3 (q = 2t):
-// out[2 qq + b] = in[qq] rl[4+b] + in[qq+1] rl[2+b] + in[qq+2] rl[b]
-__device__ __forceinline__ void final_xsynth(float2 lo, float2 hi, float (&o)[4]) {
+// out[2 qq + b] = in[qq] rl[4+b] + in[qq+1] rl[2+b] + in[qq+2] rl[b]; columns (0,1) and (2,3) as packed pairs
+__device__ __forceinline__ void final_xsynth(float2 lo, float2 hi, dsx_f2 (&o)[2]) {
   constexpr float RL[6] = DSX_REC_LO;
-  o[0] = fmaf(lo.x, RL[4], fmaf(lo.y, RL[2], hi.x * RL[0]));
-  o[1] = fmaf(lo.x, RL[5], fmaf(lo.y, RL[3], hi.x * RL[1]));
-  o[2] = fmaf(lo.y, RL[4], fmaf(hi.x, RL[2], hi.y * RL[0]));
-  o[3] = fmaf(lo.y, RL[5], fmaf(hi.x, RL[3], hi.y * RL[1]));
+  const dsx_f2 t45 = {RL[4], RL[5]}, t23 = {RL[2], RL[3]}, t01 = {RL[0], RL[1]};
+  o[0] = pk_fma(lo.x, t45, pk_fma(lo.y, t23, hi.x * t01));
+  o[1] = pk_fma(lo.y, t45, pk_fma(hi.x, t23, hi.y * t01));
+}
+// a0 t0 + a1 t1 + a2 t2 + d0 u0 + d1 u1 + d2 u2, accumulated left to right
+__device__ __forceinline__ dsx_f2 pk_dot6(dsx_f2 a0, float t0, dsx_f2 a1, float t1, dsx_f2 a2, float t2,
+                                          dsx_f2 d0, float u0, dsx_f2 d1, float u1, dsx_f2 d2, float u2) {
+  dsx_f2 v = a0 * t0;
+  v = pk_fma(a1, t1, v);
+  v = pk_fma(a2, t2, v);
+  v = pk_fma(d0, u0, v);
+  v = pk_fma(d1, u1, v);
+  v = pk_fma(d2, u2, v);
+  return v;
 }
 
 // c0l = c0 * log2(e) (the factor is folded into the axis-0 synthesis taps of the last level)
@@ -1480,7 +1586,7 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
   const bool l2_lane = FUSE && lane < 33 && (kMarchCols / 2) * strip + 4 * lane < a.wc + 4;
   const float* c2base = FUSE ? a.ws + plane * a.ws_plane_stride + a.c2_off : nullptr;
   const float* d2base = FUSE ? a.ws + plane * a.ws_plane_stride + a.d2_off : nullptr;
-  float A2[3][4], D2[3][4];
+  dsx_f2 A2[3][2], D2[3][2];
   FinalRawC n2;
   int next_P = 0, c1_ready = 0;  // c_1 rows < c1_ready are in the ring
   auto l2_load = [&](int P2) {
@@ -1503,23 +1609,19 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     final_xsynth(n2.c01, n2.c23, A2[2]);
     final_xsynth(n2.d01, n2.d23, D2[2]);
     n2 = l2_load(P + 3);
-    float ev[4], od[4];
+    dsx_f2 ev[2], od[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v0 = A2[0][e] * RL0[4];
-      v0 = fmaf(A2[1][e], RL0[2], v0); v0 = fmaf(A2[2][e], RL0[0], v0);
-      v0 = fmaf(D2[0][e], RH0[4], v0); v0 = fmaf(D2[1][e], RH0[2], v0); v0 = fmaf(D2[2][e], RH0[0], v0);
-      float v1 = A2[0][e] * RL0[5];
-      v1 = fmaf(A2[1][e], RL0[3], v1); v1 = fmaf(A2[2][e], RL0[1], v1);
-      v1 = fmaf(D2[0][e], RH0[5], v1); v1 = fmaf(D2[1][e], RH0[3], v1); v1 = fmaf(D2[2][e], RH0[1], v1);
-      ev[e] = v0;
-      od[e] = v1;
-      A2[0][e] = A2[1][e]; A2[1][e] = A2[2][e];
-      D2[0][e] = D2[1][e]; D2[1][e] = D2[2][e];
+    for (int h = 0; h < 2; ++h) {
+      ev[h] = pk_dot6(A2[0][h], RL0[4], A2[1][h], RL0[2], A2[2][h], RL0[0], D2[0][h], RH0[4], D2[1][h], RH0[2],
+                      D2[2][h], RH0[0]);
+      od[h] = pk_dot6(A2[0][h], RL0[5], A2[1][h], RL0[3], A2[2][h], RL0[1], D2[0][h], RH0[5], D2[1][h], RH0[3],
+                      D2[2][h], RH0[1]);
+      A2[0][h] = A2[1][h]; A2[1][h] = A2[2][h];
+      D2[0][h] = D2[1][h]; D2[1][h] = D2[2][h];
     }
     if (lane < 33) {
-      *(float4*)&s_c1[(2 * P) & (kRingRows - 1)][4 * lane] = make_float4(ev[0], ev[1], ev[2], ev[3]);
-      *(float4*)&s_c1[(2 * P + 1) & (kRingRows - 1)][4 * lane] = make_float4(od[0], od[1], od[2], od[3]);
+      *(float4*)&s_c1[(2 * P) & (kRingRows - 1)][4 * lane] = make_float4(ev[0].x, ev[0].y, ev[1].x, ev[1].y);
+      *(float4*)&s_c1[(2 * P + 1) & (kRingRows - 1)][4 * lane] = make_float4(od[0].x, od[0].y, od[1].x, od[1].y);
     }
     wave_sync();
   };
@@ -1581,7 +1683,7 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     return r;
   };
 
-  float A[3][4], D[3][4];  // row-synthesised c and Delta rows p, p+1, p+2 (window)
+  dsx_f2 A[3][2], D[3][2];  // row-synthesised c and Delta rows p, p+1, p+2 (window), columns as packed pairs
   {
     FinalRawC r0 = issue_c(p_begin), r1 = issue_c(p_begin + 1);
     if (FUSE) {
@@ -1594,7 +1696,8 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     final_xsynth(r1.d01, r1.d23, D[1]);
   }
 
-  auto emit_row = [&](int gy, const FinalRawI<IN_KIND>& raw, const float (&c0)[4]) {
+  auto emit_row = [&](int gy, const FinalRawI<IN_KIND>& raw, const dsx_f2 (&c0p)[2]) {
+    const float c0[4] = {c0p[0].x, c0p[0].y, c0p[1].x, c0p[1].y};
     if (gy >= a.hout) return;
     if (IN_KIND == 2) {
       float* dst = a.ws_out + plane * a.ws_plane_stride + a.out_off + (long long)gy * a.ldout + x0;
@@ -1664,24 +1767,18 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
 
   // one coefficient row p -> result rows 2p, 2p+1; (A0, A1, A2) = window rows p, p+1, p+2
   auto step = [&](int p, const FinalRawC& rc_in, const FinalRawI<IN_KIND>& ri0, const FinalRawI<IN_KIND>& ri1,
-                  float (&A0)[4], float (&A1)[4], float (&A2)[4], float (&D0)[4], float (&D1)[4],
-                  float (&D2)[4]) {
+                  dsx_f2 (&A0)[2], dsx_f2 (&A1)[2], dsx_f2 (&A2)[2], dsx_f2 (&D0)[2], dsx_f2 (&D1)[2],
+                  dsx_f2 (&D2)[2]) {
     FinalRawC rc = rc_in;
     if (FUSE) ring_c(p + 2, rc);
     final_xsynth(rc.c01, rc.c23, A2);
     final_xsynth(rc.d01, rc.d23, D2);
-    float even[4], odd[4];
+    dsx_f2 even[2], odd[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      // out[2p + b] = sum_j A[p+j] rl[4 - 2j + b] + D[p+j] rh[4 - 2j + b]
-      float v0 = A0[e] * RL[4];
-      v0 = fmaf(A1[e], RL[2], v0); v0 = fmaf(A2[e], RL[0], v0);
-      v0 = fmaf(D0[e], RH[4], v0); v0 = fmaf(D1[e], RH[2], v0); v0 = fmaf(D2[e], RH[0], v0);
-      float v1 = A0[e] * RL[5];
-      v1 = fmaf(A1[e], RL[3], v1); v1 = fmaf(A2[e], RL[1], v1);
-      v1 = fmaf(D0[e], RH[5], v1); v1 = fmaf(D1[e], RH[3], v1); v1 = fmaf(D2[e], RH[1], v1);
-      even[e] = v0;
-      odd[e] = v1;
+    for (int h = 0; h < 2; ++h) {
+      // out[2p + b] = sum_j A[p+j] rl[4 - 2j + b] + D[p+j] rh[4 - 2j + b], two columns per instruction
+      even[h] = pk_dot6(A0[h], RL[4], A1[h], RL[2], A2[h], RL[0], D0[h], RH[4], D1[h], RH[2], D2[h], RH[0]);
+      odd[h] = pk_dot6(A0[h], RL[5], A1[h], RL[3], A2[h], RL[1], D0[h], RH[5], D1[h], RH[3], D2[h], RH[1]);
     }
     emit_row(2 * p, ri0, even);
     emit_row(2 * p + 1, ri1, odd);
