@@ -1578,6 +1578,10 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
   // pyramid levels write into padded aa rows: a 16-byte store may run into the margin columns
   const bool vec_out = ((out_pitch & 3) == 0) && ((IN_KIND == 2) ? (x0 + 3 < a.wout + 8) : (x0 + 3 < a.wout));
   const long long img_plane = plane * a.img_plane_stride;
+  // flat / dark rows as aligned float4 loads when the pitches and base addresses allow it (wave-uniform)
+  const int xs = min(x0, max(a.wout - 4, 0));
+  const bool shade_vec = SHADE && (a.wout & 3) == 0 && (a.dark_ld & 3) == 0 && a.wout >= 4 &&
+                         (((uintptr_t)a.dark | (uintptr_t)a.flat) & 15) == 0;
 
   // ---- FUSE: c_1 rows from level 2, lanes 0..32 (4 columns each), into the per-wave LDS ring ----------
   // One step P loads level-2 row P + 2 and emits c_1 rows 2P, 2P + 1 (plain taps: c_1 is a log-image
@@ -1729,11 +1733,18 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     }
     float dk[4] = {0.f, 0.f, 0.f, 0.f}, fl[4] = {1.f, 1.f, 1.f, 1.f};
     if (SHADE) {
+      if (shade_vec) {  // one 16-byte load per plane and lane (clamped address for lanes right of the plane)
+        const float4 d4 = *(const float4*)(a.dark + (long long)gy * a.dark_ld + xs);
+        const float4 f4 = *(const float4*)(a.flat + (long long)gy * a.wout + xs);
+        dk[0] = d4.x; dk[1] = d4.y; dk[2] = d4.z; dk[3] = d4.w;
+        fl[0] = f4.x; fl[1] = f4.y; fl[2] = f4.z; fl[3] = f4.w;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int gx = min(x0 + e, a.wout - 1);
-        dk[e] = a.dark[(long long)gy * a.dark_ld + gx];
-        fl[e] = a.flat[(long long)gy * a.wout + gx];
+        for (int e = 0; e < 4; ++e) {
+          const int gx = min(x0 + e, a.wout - 1);
+          dk[e] = a.dark[(long long)gy * a.dark_ld + gx];
+          fl[e] = a.flat[(long long)gy * a.wout + gx];
+        }
       }
     }
     float r[4];
