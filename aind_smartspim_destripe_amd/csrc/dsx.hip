@@ -19,6 +19,7 @@
 #include "dsx_kernels.h"
 #include "dsx_retile.h"
 #include "dsx_plan.h"
+#include "dsx_io.h"
 
 namespace {
 
@@ -91,6 +92,8 @@ struct dsx_ctx {
   // copy streams of the overlapped chunk map (dsx_memcpy_*_async): 1 = upload, 2 = download
   hipStream_t copy_stream[2] = {};
   hipEvent_t ev_xs = nullptr;  // cross-stream ordering (dsx_stream_wait)
+  static constexpr int kEventSlots = 8;
+  hipEvent_t ev_slot[kEventSlots] = {};  // host-visible completion marks (dsx_event_record / dsx_event_sync)
 };
 
 namespace {
@@ -112,6 +115,7 @@ namespace {
 
 int fail(dsx_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
+  else g_init_error = msg;  // context-free calls (dsx_io_*): dsx_last_error(NULL) reports it
   return code;
 }
 
@@ -531,6 +535,8 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_xs, hipEventDisableTiming);
+  for (int i = 0; i < dsx_ctx::kEventSlots && e == hipSuccess; ++i)
+    e = hipEventCreateWithFlags(&c->ev_slot[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&c->t0);
   if (e == hipSuccess) e = hipEventCreate(&c->t1);
   if (e != hipSuccess) {
@@ -559,6 +565,8 @@ void dsx_destroy(dsx_ctx* ctx) {
   for (int i = 0; i < 2; ++i)
     if (ctx->copy_stream[i]) { (void)hipStreamSynchronize(ctx->copy_stream[i]); (void)hipStreamDestroy(ctx->copy_stream[i]); }
   if (ctx->ev_xs) (void)hipEventDestroy(ctx->ev_xs);
+  for (int i = 0; i < dsx_ctx::kEventSlots; ++i)
+    if (ctx->ev_slot[i]) (void)hipEventDestroy(ctx->ev_slot[i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -828,6 +836,18 @@ int dsx_stream_wait(dsx_ctx* ctx, int waiter, int signaller) {
   DSX_HIP(hipSetDevice(ctx->device));
   DSX_HIP(hipEventRecord(ctx->ev_xs, pick_stream(ctx, signaller)));
   DSX_HIP(hipStreamWaitEvent(pick_stream(ctx, waiter), ctx->ev_xs, 0));
+  return DSX_OK;
+}
+int dsx_event_record(dsx_ctx* ctx, int slot, int stream_id) {
+  if (!ctx || slot < 0 || slot >= dsx_ctx::kEventSlots || !stream_id_ok(stream_id)) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipEventRecord(ctx->ev_slot[slot], pick_stream(ctx, stream_id)));
+  return DSX_OK;
+}
+int dsx_event_sync(dsx_ctx* ctx, int slot) {
+  if (!ctx || slot < 0 || slot >= dsx_ctx::kEventSlots) return DSX_EINVAL;
+  DSX_HIP(hipSetDevice(ctx->device));
+  DSX_HIP(hipEventSynchronize(ctx->ev_slot[slot]));
   return DSX_OK;
 }
 int dsx_stream_sync(dsx_ctx* ctx, int stream_id) {
@@ -1103,6 +1123,22 @@ int dsx_comm_allreduce_f64(dsx_ctx* ctx, double* values, int n, int op) {
   DSX_NCCL(g_rccl.all_reduce(ctx->d_red, ctx->d_red, n, ncclDouble, ops[op], ctx->comm, ctx->stream));
   DSX_HIP(hipMemcpyAsync(values, ctx->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   DSX_HIP(hipStreamSynchronize(ctx->stream));
+  return DSX_OK;
+}
+
+/* ---- chunk files <-> staging memory on native threads (dsx_io.h) -------------------------------- */
+int dsx_io_read_chunks(dsx_ctx* ctx, const char* const* paths, void* const* dst, const size_t* bytes, int n,
+                       int threads, int zlib_chunks, uint16_t fill_value) {
+  if (n < 0 || (n > 0 && (!paths || !dst || !bytes))) return DSX_EINVAL;
+  const std::string e = dsx::io_read_chunks(paths, dst, bytes, n, threads, zlib_chunks != 0, fill_value);
+  if (!e.empty()) return fail(ctx, DSX_EIO, e);
+  return DSX_OK;
+}
+int dsx_io_write_chunks(dsx_ctx* ctx, const char* const* paths, const void* const* src, const size_t* bytes, int n,
+                        int threads, int zlib_level) {
+  if (n < 0 || (n > 0 && (!paths || !src || !bytes))) return DSX_EINVAL;
+  const std::string e = dsx::io_write_chunks(paths, src, bytes, n, threads, zlib_level);
+  if (!e.empty()) return fail(ctx, DSX_EIO, e);
   return DSX_OK;
 }
 

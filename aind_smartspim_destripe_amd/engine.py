@@ -20,7 +20,7 @@ STAGE_APPROX, STAGE_DETAIL = 0, 1
 STREAM_COMPUTE, STREAM_UPLOAD, STREAM_DOWNLOAD = 0, 1, 2
 COMM_ID_BYTES = 128
 _ERRORS = {-1: "DSX_EINVAL", -2: "DSX_ENOPLAN", -3: "DSX_EHIP", -4: "DSX_ENOMEM", -5: "DSX_ELIMIT",
-           -6: "DSX_ECOMM"}  # fmt: skip
+           -6: "DSX_ECOMM", -7: "DSX_EIO"}  # fmt: skip
 
 # every symbol include/dsx.h declares (tests/test_host_native.py checks the list against the header)
 EXPORTED_SYMBOLS = [
@@ -33,7 +33,8 @@ EXPORTED_SYMBOLS = [
     "dsx_flatfield_correction", "dsx_foreground_background",
     "dsx_comm_unique_id", "dsx_comm_init", "dsx_comm_destroy", "dsx_comm_broadcast", "dsx_comm_allreduce_f64",
     "dsx_malloc_host", "dsx_free_host", "dsx_memcpy_h2d_async", "dsx_memcpy_d2h_async",
-    "dsx_stream_wait", "dsx_stream_sync",
+    "dsx_stream_wait", "dsx_stream_sync", "dsx_event_record", "dsx_event_sync",
+    "dsx_io_read_chunks", "dsx_io_write_chunks",
 ]  # fmt: skip
 
 
@@ -134,6 +135,12 @@ def load_library(path=None):
     lib.dsx_memcpy_d2h_async.argtypes = [vp, vp, vp, ctypes.c_size_t, i32]
     lib.dsx_stream_wait.argtypes = [vp, i32, i32]
     lib.dsx_stream_sync.argtypes = [vp, i32]
+    lib.dsx_event_record.argtypes = [vp, i32, i32]
+    lib.dsx_event_sync.argtypes = [vp, i32]
+    lib.dsx_io_read_chunks.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
+                                       ctypes.POINTER(ctypes.c_size_t), i32, i32, i32, ctypes.c_uint16]  # fmt: skip
+    lib.dsx_io_write_chunks.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
+                                        ctypes.POINTER(ctypes.c_size_t), i32, i32, i32]  # fmt: skip
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("dsx_destroy", "dsx_last_error"):
@@ -395,6 +402,33 @@ class DestripeEngine:
 
     def stream_sync(self, stream):
         self._check(self._lib.dsx_stream_sync(self._ctx, int(stream)))
+
+    # -- chunk files on native threads (dsx_io.h); ctypes releases the GIL for the call -----------
+    def io_read_chunks(self, paths, arrays, threads=16, zlib_chunks=False, fill_value=0):
+        """Chunk files ``paths[i]`` -> ``arrays[i]`` (C-contiguous NumPy arrays of the decompressed chunk size)."""
+        n = len(paths)
+        cp = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        dp = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
+        nb = (ctypes.c_size_t * n)(*[a.nbytes for a in arrays])
+        self._check(self._lib.dsx_io_read_chunks(self._ctx, cp, dp, nb, n, int(threads), 1 if zlib_chunks else 0,
+                                                 int(fill_value)))  # fmt: skip
+
+    def io_write_chunks(self, paths, arrays, threads=16, zlib_level=-1):
+        """``arrays[i]`` -> chunk files ``paths[i]`` (raw, or zlib streams for ``zlib_level >= 0``), atomically."""
+        n = len(paths)
+        cp = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        dp = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
+        nb = (ctypes.c_size_t * n)(*[a.nbytes for a in arrays])
+        self._check(self._lib.dsx_io_write_chunks(self._ctx, cp, dp, nb, n, int(threads), int(zlib_level)))
+
+    def event_record(self, slot, stream):
+        self._check(self._lib.dsx_event_record(self._ctx, int(slot), int(stream)))
+
+    def event_sync(self, slot):
+        self._check(self._lib.dsx_event_sync(self._ctx, int(slot)))
+
+    def copy_d2d_async(self, d_dst, d_src, nbytes):
+        self._check(self._lib.dsx_memcpy_d2d(self._ctx, ctypes.c_void_p(d_dst.ptr), ctypes.c_void_p(d_src.ptr), int(nbytes)))
 
     def profile(self, on):
         self._check(self._lib.dsx_profile_enable(self._ctx, 1 if on else 0))

@@ -36,6 +36,7 @@ class MiniZarrArray:
         if meta.get("order", "C") != "C" or meta.get("filters"):
             raise NotImplementedError("only C-order arrays without filters are supported")
         self.ndim = len(self.shape)
+        self._dirs_made = set()
 
     # -- construction -------------------------------------------------------------------------
     @classmethod
@@ -60,14 +61,23 @@ class MiniZarrArray:
             "filters": None,
             "dimension_separator": dimension_separator,
         }
-        with open(os.path.join(path, ".zarray"), "w") as f:
+        # written to a temporary name and renamed: a concurrent reader (another rank polling for the array)
+        # sees the metadata either whole or not at all
+        tmp = os.path.join(path, ".zarray.tmp.{}".format(os.getpid()))
+        with open(tmp, "w") as f:
             json.dump(meta, f)
+        os.replace(tmp, os.path.join(path, ".zarray"))
         return cls(path, meta)
 
     @classmethod
     def open(cls, path):
         with open(os.path.join(path, ".zarray")) as f:
             return cls(path, json.load(f))
+
+    def matches(self, shape, chunks, dtype):
+        """Does this array have the given geometry (used to tell a freshly created array from a stale one)?"""
+        return (self.shape == tuple(int(x) for x in shape) and self.chunks == tuple(int(x) for x in chunks)
+                and self.dtype == np.dtype(dtype))
 
     # -- chunk io -----------------------------------------------------------------------------
     def _chunk_path(self, idx):
@@ -86,13 +96,20 @@ class MiniZarrArray:
     def read_chunk_into(self, idx, out_flat):
         """Decompressed chunk ``idx`` (the whole brick, as stored) into a flat array of chunk size."""
         p = self._chunk_path(idx)
-        if not os.path.exists(p):
+        try:
+            f = open(p, "rb", buffering=0)
+        except FileNotFoundError:
             out_flat[...] = self.fill_value
             return
-        with open(p, "rb") as f:
-            raw = f.read()
-        if self.compressor is not None:
-            raw = zlib.decompress(raw)
+        with f:
+            if self.compressor is None:
+                # raw chunk: straight into the (pinned) staging buffer, one copy, no GIL held by the read
+                view = memoryview(out_flat).cast("B")
+                got = f.readinto(view)
+                if got != len(view):
+                    raise ValueError("chunk {} has {} bytes, expected {}".format(p, got, len(view)))
+                return
+            raw = zlib.decompress(f.read())
         out_flat[...] = np.frombuffer(raw, dtype=self.dtype)
 
     def write_chunk_flat(self, idx, flat):
@@ -101,11 +118,14 @@ class MiniZarrArray:
 
     def _write_chunk(self, idx, block):
         p = self._chunk_path(idx)
-        os.makedirs(os.path.dirname(p), exist_ok=True)
-        raw = np.ascontiguousarray(block, dtype=self.dtype).tobytes()
+        d = os.path.dirname(p)
+        if d not in self._dirs_made:
+            os.makedirs(d, exist_ok=True)
+            self._dirs_made.add(d)
+        raw = memoryview(np.ascontiguousarray(block, dtype=self.dtype)).cast("B")
         if self.compressor is not None:
             raw = zlib.compress(raw, self.compressor[1])
-        with open(p + ".tmp", "wb") as f:
+        with open(p + ".tmp", "wb", buffering=0) as f:
             f.write(raw)
         os.replace(p + ".tmp", p)
 

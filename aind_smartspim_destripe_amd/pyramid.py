@@ -59,21 +59,53 @@ def compute_pyramid(data, n_lvls, scale_axis, chunks="auto", device=0, engine=No
 
 
 def compute_multiscale(level0_path, group_path, scale_factor=(2, 2, 2), n_levels=3, chunks=(1, 1, 64, 128, 128),
-                       compressor=None, device=0):  # fmt: skip
+                       compressor=None, device=0, slab_planes=None):  # fmt: skip
     """Level loop of ``compute_multiscale`` (``zarr_destriper.py:746-782``) over Zarr-v2 directory stores:
-    reads level 0, writes ``<group_path>/<i>`` for ``i = 1 .. n_levels - 1`` (uint16, ``"/"`` separator).
-    OME-NGFF metadata (``:728-742``) is out of scope.  Returns the written arrays' shapes.
+    writes ``<group_path>/<i>`` for ``i = 1 .. n_levels - 1`` (uint16, ``"/"`` separator), every level from the
+    previous one.  OME-NGFF metadata (``:728-742``) is out of scope.  Returns the written arrays' shapes.
+
+    The volume is streamed in z-slabs (a 34 GB channel does not fit one allocation, nor host RAM twice):
+    a slab of ``2 * output z-chunk`` source planes is read, reduced by one ``dsx_downsample2_u16`` launch
+    and written as whole output chunks; the 2 x 2 x 2 windows never straddle a slab because slabs start
+    at even planes.
     """
     import os
 
-    src = MiniZarrArray.open(level0_path)
-    vol = src[(slice(None),) * src.ndim]
-    pyr = compute_pyramid(vol, n_levels, (1,) * (vol.ndim - 3) + tuple(scale_factor), device=device)
+    _check_scale((1,) * 2 + tuple(scale_factor))
+    eng = _engine.DestripeEngine(device)
     shapes = []
-    for i, lvl in enumerate(pyr[1:], start=1):
-        ck = tuple(min(c, n) for c, n in zip(chunks[-lvl.ndim :], lvl.shape))
-        dst = MiniZarrArray.create(os.path.join(group_path, str(i)), lvl.shape, ck, np.uint16, compressor=compressor,
-                                   dimension_separator="/")  # fmt: skip
-        dst[(slice(None),) * lvl.ndim] = lvl
-        shapes.append(lvl.shape)
+    try:
+        src_path = level0_path
+        for i in range(1, int(n_levels)):
+            src = MiniZarrArray.open(src_path)
+            if src.dtype != np.uint16 or any(n != 1 for n in src.shape[:-3]):
+                raise ValueError("the pyramid kernel takes uint16 volumes with singleton leading axes")
+            Z, Y, X = src.shape[-3:]
+            if min(Z, Y, X) < 2:
+                break
+            out_zyx = (Z // 2, Y // 2, X // 2)
+            lead = src.shape[:-3]
+            out_shape = lead + out_zyx
+            ck = tuple(min(c, n) for c, n in zip(tuple(chunks)[-len(out_shape):], out_shape))
+            dst = MiniZarrArray.create(os.path.join(group_path, str(i)), out_shape, ck, np.uint16,
+                                       compressor=compressor, dimension_separator="/")  # fmt: skip
+            slab = int(slab_planes) if slab_planes else 2 * ck[-3]
+            slab += slab & 1
+            d_src = eng.alloc(slab * Y * X * 2)
+            d_dst = eng.alloc(max((slab // 2) * out_zyx[1] * out_zyx[2] * 2, 16))
+            try:
+                lead_idx = (0,) * len(lead)
+                for z in range(0, 2 * out_zyx[0], slab):
+                    n = min(slab, 2 * out_zyx[0] - z)  # even: an odd trailing plane is cropped
+                    d_src.upload(src[lead_idx + (slice(z, z + n),)])
+                    eng.downsample2(d_src, d_dst, (n, Y, X))
+                    out = d_dst.download((n // 2,) + out_zyx[1:], np.uint16)
+                    dst[lead_idx + (slice(z // 2, z // 2 + n // 2),)] = out
+            finally:
+                d_src.free()
+                d_dst.free()
+            shapes.append(out_shape)
+            src_path = os.path.join(group_path, str(i))
+    finally:
+        eng.close()
     return shapes

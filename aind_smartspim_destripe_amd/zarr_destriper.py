@@ -61,86 +61,88 @@ def _natsorted(names):
     return sorted(names, key=key)
 
 
-def get_microscope_flats(channel_name: str, derivatives_folder):
-    """``zarr_destriper.py:70-154``: the two ``FlatReal<wavelength>_*.tif`` planes of a channel (one per brain
-    hemisphere) and ``{X folder: {Y folder: side}}`` from ``metadata.json``.
+def _emission_wavelength(channel_name):
+    """First all-digit token of ``Ex_561_Em_593``-style channel names, or ``None``."""
+    for token in str(channel_name).split("_"):
+        if token.isdigit():
+            return int(token)
+    return None
 
-    ``(None, None)`` when there is no ``metadata.json`` or the channel name holds no wavelength;
-    ``ValueError`` without ``tile_config`` or when the number of flats is not 2; ``KeyError`` for a tile
-    entry without ``X`` / ``Y`` / ``Side``.
+
+def _tile_sides(tile_config, wavelength):
+    """``{X folder: {Y folder: brain side}}`` of the tiles imaged with ``wavelength``."""
+    sides = {}
+    for entry in tile_config.values():
+        if int(entry.get("Laser")) != wavelength:
+            continue
+        try:
+            x_folder, y_folder, side = (entry[k] for k in ("X", "Y", "Side"))
+            if x_folder is None or y_folder is None or side is None:
+                raise KeyError
+        except KeyError:
+            raise KeyError("Please, check the data in metadata.json") from None
+        sides.setdefault(x_folder, {})[y_folder] = int(side)
+    return sides
+
+
+def get_microscope_flats(channel_name: str, derivatives_folder):
+    """Microscope flats of a channel (reference ``zarr_destriper.py:70-154``).
+
+    Returns ``([flat of side 0, flat of side 1], {X folder: {Y folder: side}})`` read from
+    ``<derivatives>/FlatReal<wavelength>_*.tif`` (natural file order) and ``metadata.json``'s ``tile_config``;
+    ``(None, None)`` when there is no ``metadata.json`` or the channel name holds no wavelength.
+    ``ValueError`` without ``tile_config`` or unless exactly two flats exist; ``KeyError`` for a tile entry
+    without ``X`` / ``Y`` / ``Side``.
     """
-    flatfield = None
-    metadata_json = None
-    derivatives_folder = Path(derivatives_folder)
-    waves = [p for p in str(channel_name).split("_") if p.isdigit()]
-    metadata_json_path = derivatives_folder.joinpath("metadata.json")
-    if metadata_json_path.exists() and len(waves):
-        orig_metadata_json = read_json_as_dict(filepath=metadata_json_path)
-        curr_emision_wave = int(waves[0])
-        tile_config = orig_metadata_json.get("tile_config")
-        metadata_json = {}
-        if tile_config is None:
-            raise ValueError("Please, verify metadata.json")
-        for time_step, value in tile_config.items():
-            if int(value.get("Laser")) == curr_emision_wave:
-                x_folder, y_folder, brain_side = value.get("X"), value.get("Y"), value.get("Side")
-                if x_folder is None or y_folder is None or brain_side is None:
-                    raise KeyError("Please, check the data in metadata.json")
-                if metadata_json.get(x_folder) is None:
-                    metadata_json[x_folder] = {}
-                metadata_json[x_folder][y_folder] = int(brain_side)
-        flatfield = [
-            tif.imread(g)
-            for g in _natsorted(glob(f"{derivatives_folder}/FlatReal{curr_emision_wave}_*.tif"))
-            if os.path.exists(g)
-        ]
-        if len(flatfield) != 2:
-            raise ValueError(f"Error while reading the microscope flatfields: {flatfield}")
-    return flatfield, metadata_json
+    folder = Path(derivatives_folder)
+    wavelength = _emission_wavelength(channel_name)
+    meta_path = folder / "metadata.json"
+    if wavelength is None or not meta_path.exists():
+        return None, None
+    tile_config = read_json_as_dict(filepath=meta_path).get("tile_config")
+    if tile_config is None:
+        raise ValueError("Please, verify metadata.json")
+    sides = _tile_sides(tile_config, wavelength)
+    flat_files = _natsorted(glob(f"{folder}/FlatReal{wavelength}_*.tif"))
+    flats = [tif.imread(f) for f in flat_files if os.path.exists(f)]
+    if len(flats) != 2:
+        raise ValueError(f"Error while reading the microscope flatfields: {flats}")
+    return flats, sides
 
 
 def load_shadow_correction(derivatives_path, output_destriped_zarr, flatfield=None, logger=None):
-    """The ``shadow_correction`` dict exactly as ``destripe_zarr`` assembles it (``zarr_destriper.py:1095-1130``):
-    the microscope dark (``DarkMaster_cropped.tif``, ``FileNotFoundError`` if absent), and either the given
-    retrospective flat or the normalised microscope flats with their tile config.
+    """The ``shadow_correction`` dict ``destripe_zarr`` hands to the filter (reference ``zarr_destriper.py:1095-1130``).
+
+    ``darkfield`` = ``<derivatives>/DarkMaster_cropped.tif`` (``FileNotFoundError`` with the reference's message if
+    the folder exists but the file does not; ``None`` if there is no derivatives folder at all).  A given
+    ``flatfield`` is the retrospective one; otherwise the microscope flats of the channel (the folder above
+    the tile) are loaded, normalised, and returned with their tile config.
     """
-    logger = logger or logging.getLogger("dsx.zarr")
-    derivatives_path = Path(derivatives_path)
-    darkfield = None
-    tile_config = None
-    retrospective = False if flatfield is None else True
-    if os.path.exists(derivatives_path):
-        darkfield_path = str(derivatives_path.joinpath("DarkMaster_cropped.tif"))
-        logger.info(f"Loading darkfield from path: {darkfield_path}")
-        try:
-            darkfield = tif.imread(darkfield_path)
-        except FileNotFoundError:
-            raise FileNotFoundError(
-                f"Please, provide the current dark from the microscope! Provided path: {darkfield_path}"
-            )
-        if flatfield is None:
-            channel_name = Path(output_destriped_zarr).parent.name
-            flatfield, tile_config = get_microscope_flats(
-                channel_name=str(channel_name), derivatives_folder=derivatives_path
-            )
-            flatfield = fl.normalize_image(flatfield)
-        else:
-            logger.info("Ignoring microscope flats...")
-    return {
-        "retrospective": retrospective,
-        "flatfield": flatfield,
-        "darkfield": darkfield,
-        "tile_config": tile_config,
-    }
+    log = logger or logging.getLogger("dsx.zarr")
+    folder = Path(derivatives_path)
+    correction = {"retrospective": flatfield is not None, "flatfield": flatfield, "darkfield": None, "tile_config": None}
+    if not os.path.exists(folder):
+        return correction
+    dark_file = str(folder / "DarkMaster_cropped.tif")
+    log.info(f"Loading darkfield from path: {dark_file}")
+    if not os.path.exists(dark_file):
+        raise FileNotFoundError(f"Please, provide the current dark from the microscope! Provided path: {dark_file}")
+    correction["darkfield"] = tif.imread(dark_file)
+    if flatfield is not None:
+        log.info("Ignoring microscope flats...")
+        return correction
+    channel = Path(output_destriped_zarr).parent.name
+    flats, correction["tile_config"] = get_microscope_flats(channel_name=str(channel), derivatives_folder=folder)
+    correction["flatfield"] = fl.normalize_image(flats)
+    return correction
 
 
 def pad_array_n_d(arr, dim: int = 5):
-    """``zarr_destriper.py:157-179``: prepend singleton axes up to ``dim`` (at most 5)."""
+    """Leading singleton axes up to ``dim`` dimensions (reference ``zarr_destriper.py:157-179``; at most 5)."""
     if dim > 5:
         raise ValueError("Padding more than 5 dimensions is not supported.")
-    while arr.ndim < dim:
-        arr = arr[np.newaxis, ...]
-    return arr
+    missing = max(0, dim - arr.ndim)
+    return arr.reshape((1,) * missing + arr.shape)
 
 
 def recover_global_position(super_chunk_slice, internal_slices):
@@ -244,47 +246,126 @@ def iter_blocks(zyx_shape, prediction_chunksize, z_range=None):
 
 
 class _DeviceBlocks:
-    """Brick-order staging + device re-tiling for one rank (row f1)."""
+    """Brick-order staging + device re-tiling for one rank (row f1), software-pipelined.
+
+    The reference keeps ``CO_CPUS`` consumer processes busy behind a bounded queue while the producer
+    reads ahead (``zarr_destriper.py:797-906, 1138-1172``).  Here the same overlap is three HIP streams
+    and two sets of buffers: while block ``b`` is being filtered on the compute stream, the chunks of
+    block ``b + 1`` are read / decompressed by the I/O threads and uploaded on the upload stream, and the
+    bricks of block ``b - 1`` are downloaded on the download stream and compressed / written by the I/O
+    threads.  Host staging is page-locked (``dsx_malloc_host``), so the copies are asynchronous.
+
+    Ordering (``dsx_stream_wait`` = event record + stream wait, nothing blocks the host):
+    upload(b) -> compute(b) -> download(b);  upload(b + 2) after compute(b) (it refills the same device
+    buffer);  compute(b + 2) after download(b) (it overwrites the same output bricks).  The host waits on
+    event slots before it refills a pinned input buffer or hands a pinned output buffer to the writers.
+    """
+
+    N_BUF = 2
 
     def __init__(self, eng, src, dst, zyx, block_z, io_threads):
-        self.eng, self.src, self.dst, self.zyx = eng, src, dst, zyx
+        self.eng, self.src, self.dst, self.zyx, self.block_z = eng, src, dst, zyx, block_z
         self.ci, self.co = tuple(src.chunks[-3:]), tuple(dst.chunks[-3:])
         _, H, W = zyx
         grid = lambda c, zspan: (-(-zspan // c[0]), -(-H // c[1]), -(-W // c[2]))  # noqa: E731
         self.gi = grid(self.ci, block_z + self.ci[0] - 1)  # a block may start inside an input chunk
         self.go = grid(self.co, block_z)
-        self.stage_in = np.empty(self.gi + (int(np.prod(self.ci)),), dtype=np.uint16)
+        self.in_brick = int(np.prod(self.ci))
         self.out_brick = int(np.prod(self.co))
-        self.d_bricks_in = eng.alloc(self.stage_in.nbytes)
-        self.d_bricks_out = eng.alloc(int(np.prod(self.go)) * self.out_brick * 2)
+        in_bytes = int(np.prod(self.gi)) * self.in_brick * 2
+        out_bytes = int(np.prod(self.go)) * self.out_brick * 2
+        self.h_in = [eng.alloc_host(in_bytes) for _ in range(self.N_BUF)]
+        self.h_out = [eng.alloc_host(out_bytes) for _ in range(self.N_BUF)]
+        self.stage_in = [h.array(self.gi + (self.in_brick,), np.uint16) for h in self.h_in]
+        self.stage_out = [h.array(self.go + (self.out_brick,), np.uint16) for h in self.h_out]
+        self.d_bricks_in = [eng.alloc(in_bytes) for _ in range(self.N_BUF)]
+        self.d_bricks_out = [eng.alloc(out_bytes) for _ in range(self.N_BUF)]
         self.d_planes = eng.alloc(block_z * H * W * 2)
         self.d_out = eng.alloc(block_z * H * W * 2)
-        self.pool = ThreadPoolExecutor(max_workers=io_threads)
+        self.io_threads = int(io_threads)
+        self.timing = {"read_s": 0.0, "write_s": 0.0}
 
     def close(self):
-        self.pool.shutdown()
-        for b in (self.d_bricks_in, self.d_bricks_out, self.d_planes, self.d_out):
+        for b in self.d_bricks_in + self.d_bricks_out + [self.d_planes, self.d_out] + self.h_in + self.h_out:
             b.free()
 
-    def run(self, z0, z1):
-        """Planes ``[z0, z1)``: read bricks -> HBM -> planes -> filter -> bricks -> store."""
-        eng, (_, H, W), Z = self.eng, self.zyx, z1 - z0
-        lead_i = (0,) * (self.src.ndim - 3)
-        lead_o = (0,) * (self.dst.ndim - 3)
+    # -- host stages (I/O threads) -------------------------------------------------------------
+    def _read(self, z0, z1, k):
+        """Decompress the input chunks of planes ``[z0, z1)`` into pinned buffer ``k``."""
+        t0 = time.perf_counter()
+        lead = (0,) * (self.src.ndim - 3)
         bz0, zoff = divmod(z0, self.ci[0])
-        nbz = -(-(zoff + Z) // self.ci[0])
+        nbz = -(-(zoff + (z1 - z0)) // self.ci[0])
         idx = list(itertools.product(range(nbz), range(self.gi[1]), range(self.gi[2])))
-        list(self.pool.map(lambda i: self.src.read_chunk_into(lead_i + (bz0 + i[0], i[1], i[2]), self.stage_in[i]), idx))
-        self.d_bricks_in.upload(self.stage_in[:nbz])
-        eng.bricks_to_planes(self.d_bricks_in, self.d_planes, (Z, H, W), self.ci, zoff)
-        eng.run_device(self.d_planes, np.uint16, Z, self.d_out, np.uint16, None)
-        eng.planes_to_bricks(self.d_out, self.d_bricks_out, (Z, H, W), self.co, 0)
-        nbo = -(-Z // self.co[0])
-        out = self.d_bricks_out.download((nbo,) + self.go[1:] + (self.out_brick,), np.uint16)
+        stage = self.stage_in[k]
+        self.eng.io_read_chunks([self.src._chunk_path(lead + (bz0 + i[0], i[1], i[2])) for i in idx],
+                                [stage[i] for i in idx], threads=self.io_threads,
+                                zlib_chunks=self.src.compressor is not None, fill_value=int(self.src.fill_value))  # fmt: skip
+        self.timing["read_s"] += time.perf_counter() - t0
+        return nbz, zoff
+
+    def _write(self, z0, z1, k):
+        """Compress / store the output bricks of planes ``[z0, z1)`` from pinned buffer ``k``."""
+        t0 = time.perf_counter()
+        lead = (0,) * (self.dst.ndim - 3)
+        nbo = -(-(z1 - z0) // self.co[0])
         oz0 = z0 // self.co[0]
+        out = self.stage_out[k]
         odx = list(itertools.product(range(nbo), range(self.go[1]), range(self.go[2])))
-        list(self.pool.map(lambda i: self.dst.write_chunk_flat(lead_o + (oz0 + i[0], i[1], i[2]),
-                                                               out[i].reshape(self.dst.chunks)), odx))  # fmt: skip
+        level = -1 if self.dst.compressor is None else int(self.dst.compressor[1])
+        self.eng.io_write_chunks([self.dst._chunk_path(lead + (oz0 + i[0], i[1], i[2])) for i in odx],
+                                 [out[i] for i in odx], threads=self.io_threads, zlib_level=level)
+        self.timing["write_s"] += time.perf_counter() - t0
+
+    # -- device stage (asynchronous) -----------------------------------------------------------
+    def _submit(self, z0, z1, k, nbz, zoff):
+        from .engine import STREAM_COMPUTE as C, STREAM_DOWNLOAD as D, STREAM_UPLOAD as U
+
+        eng, (_, H, W), Z = self.eng, self.zyx, z1 - z0
+        eng.copy_h2d_async(self.d_bricks_in[k], self.stage_in[k][:nbz], U)
+        eng.event_record(k, U)            # pinned input buffer k may be refilled once this has passed
+        eng.stream_wait(C, U)             # compute(b) after upload(b)
+        eng.stream_wait(U, C)             # uploads from now on after compute(b - 1): they refill its buffer
+        eng.bricks_to_planes(self.d_bricks_in[k], self.d_planes, (Z, H, W), self.ci, zoff)
+        eng.run_device(self.d_planes, np.uint16, Z, self.d_out, np.uint16, None)
+        eng.stream_wait(C, D)             # (the wait lands before planes_to_bricks:) after download(b - 2 .. b - 1)
+        eng.planes_to_bricks(self.d_out, self.d_bricks_out[k], (Z, H, W), self.co, 0)
+        eng.stream_wait(D, C)             # download(b) after compute(b)
+        nbo = -(-Z // self.co[0])
+        eng.copy_d2h_async(self.stage_out[k][:nbo], self.d_bricks_out[k], D)
+        eng.event_record(self.N_BUF + k, D)  # pinned output buffer k holds block b once this has passed
+
+    def run_range(self, z_start, z_stop):
+        """All blocks of ``[z_start, z_stop)`` through the pipeline; returns the number of planes."""
+        blocks = [(z, min(z + self.block_z, z_stop)) for z in range(z_start, z_stop, self.block_z)]
+        nb = len(blocks)
+        reader = ThreadPoolExecutor(max_workers=1)   # stage drivers: one read and one write in flight,
+        writer = ThreadPoolExecutor(max_workers=1)   # each fanning its chunks out over the I/O pool
+        try:
+            reads = {b: reader.submit(self._read, *blocks[b], b % self.N_BUF) for b in range(min(self.N_BUF, nb))}
+            writes = []
+            for b in range(nb):
+                k = b % self.N_BUF
+                nbz, zoff = reads.pop(b).result()
+                if b >= self.N_BUF:
+                    writes[b - self.N_BUF].result()  # pinned output buffer k has been written out
+                self._submit(*blocks[b], k, nbz, zoff)
+                if b + self.N_BUF < nb:
+                    self.eng.event_sync(k)  # upload(b) has left pinned input buffer k
+                    reads[b + self.N_BUF] = reader.submit(self._read, *blocks[b + self.N_BUF], k)
+                if b >= 1:
+                    kp = (b - 1) % self.N_BUF
+                    self.eng.event_sync(self.N_BUF + kp)  # download(b - 1) complete
+                    writes.append(writer.submit(self._write, *blocks[b - 1], kp))
+            if nb:
+                self.eng.event_sync(self.N_BUF + (nb - 1) % self.N_BUF)
+                writes.append(writer.submit(self._write, *blocks[nb - 1], (nb - 1) % self.N_BUF))
+            for w in writes:
+                w.result()
+        finally:
+            reader.shutdown()
+            writer.shutdown()
+        return sum(z1 - z0 for z0, z1 in blocks)
 
 
 def _device_retile_ok(src, dst, zyx, block_z, z0, z1):
@@ -317,6 +398,7 @@ def destripe_zarr(
     device_retile=None,
     io_threads=8,
     tile_name=None,
+    group=None,
 ):
     """Chunk map of ``destripe_zarr`` (``zarr_destriper.py:909-1211``) over a Zarr-v2 directory store.
 
@@ -324,6 +406,14 @@ def destripe_zarr(
     (chunk-aligned, so no two ranks touch one output chunk).  Blocks cover the full Y x X plane in
     production (``prediction_chunksize=(64, 1600, 2000)`` == the tile, ``:1256``); smaller y/x blocks
     would change the result (the filter is per plane), so they are rejected.
+
+    Rank 0 creates the output array -- always anew, as the reference does (``overwrite=True``, ``:1065,1073``);
+    the metadata file appears atomically.  ``group`` (anything with ``barrier()``: a
+    ``distributed.RankGroup`` / ``FileRendezvous``-based barrier, or a ``torch.distributed`` wrapper)
+    orders that creation before the other ranks open the array; without a group they poll until the
+    metadata on disk has the geometry of THIS run (a stale array of another shape is never used; one of the
+    same shape is indistinguishable and harmless: rank 0 rewrites the same metadata, every rank rewrites
+    its own chunks).  ``device=None`` takes the local rank (``LOCAL_RANK``), not the global one.
 
     ``device_retile``: ``True`` = chunks are re-tiled into planes and back on the GPU (row f1; needs a
     uint16 store and chunk-aligned z blocks), ``False`` = host gather / scatter through
@@ -335,16 +425,26 @@ def destripe_zarr(
     if prediction_chunksize[1] < zyx[1] or prediction_chunksize[2] < zyx[2]:
         raise ValueError("blocks must cover whole planes: the stripe filter is a per-plane operation")
     out_shape = (1,) * (5 - len(src.shape)) + tuple(src.shape)
-    if rank == 0 and not os.path.exists(os.path.join(output_path, ".zarray")):
-        MiniZarrArray.create(output_path, out_shape, output_chunks, np.uint16, compressor=compressor,
+    out_chunks = tuple(output_chunks)[-len(out_shape):]
+    if rank == 0:
+        MiniZarrArray.create(output_path, out_shape, out_chunks, np.uint16, compressor=compressor,
                              dimension_separator="/")  # fmt: skip
-    for _ in range(600):  # other ranks wait for rank 0 to create the array
-        if os.path.exists(os.path.join(output_path, ".zarray")):
-            break
-        time.sleep(0.1)
-    dst = MiniZarrArray.open(output_path)
+    if group is not None and world_size > 1:
+        group.barrier()
+    dst = None
+    for _ in range(1200):  # without a group: wait for rank 0's metadata of this geometry
+        try:
+            dst = MiniZarrArray.open(output_path)
+            if dst.matches(out_shape, out_chunks, np.uint16):
+                break
+        except (FileNotFoundError, ValueError):
+            pass
+        dst = None
+        time.sleep(0.05)
+    if dst is None:
+        raise TimeoutError("rank {}: the output array {} was not created with shape {}".format(rank, output_path, out_shape))
     z0, z1 = z_shard(zyx[0], world_size, rank, z_chunk=output_chunks[-3])
-    dev = rank if device is None else device
+    dev = int(os.environ.get("LOCAL_RANK", rank)) if device is None else device
     # dataset_name of the reference = the tile folder (X_..._Y_....zarr), also when level "0" is opened
     name = tile_name or os.path.basename(str(dataset_path).rstrip("/"))
     n_planes, t0 = 0, time.perf_counter()
@@ -358,14 +458,13 @@ def destripe_zarr(
                             max_batch=min(block_z, 64), device=dev)  # fmt: skip
         blocks = _DeviceBlocks(eng, src, dst, zyx, block_z, io_threads)
         try:
-            for z in range(z0, z1, block_z):
-                blocks.run(z, min(z + block_z, z1))
-                n_planes += min(z + block_z, z1) - z
+            n_planes = blocks.run_range(z0, z1)
             eng.sync()
         finally:
             blocks.close()
         dt = time.perf_counter() - t0
-        logger.info("rank %d: %d planes z[%d:%d) in %.2f s (device re-tiling)", rank, n_planes, z0, z1, dt)
+        logger.info("rank %d: %d planes z[%d:%d) in %.2f s (device re-tiling, overlapped; read %.2f s, write %.2f s)",
+                    rank, n_planes, z0, z1, dt, blocks.timing["read_s"], blocks.timing["write_s"])  # fmt: skip
         return n_planes, dt
     for sc, internal in iter_blocks(zyx, prediction_chunksize, (z0, z1)):
         lead = (0,) * (len(src.shape) - 3)
@@ -396,6 +495,7 @@ def destripe_channel(
     compressor=None,
     n_levels=3,
     logger=None,
+    group=None,
 ):
     """Tile loop of ``destripe_channel`` (``zarr_destriper.py:1214-1267``) wired to the GPU chunk map.
 
@@ -405,7 +505,15 @@ def destripe_channel(
     ``<results>/destriped_data/<channel>/<tile>.zarr/0`` and, on rank 0, write pyramid levels ``1 .. n_levels - 1``
     (``compute_multiscale``, ``:1176-1192``).  ``parameters`` holds ``cells_config`` / ``no_cells_config``
     (``:972-973``).  Returns ``{tile name: planes processed by this rank}``.
+
+    ``world_size > 1`` needs ``group`` (anything with ``barrier()``): the pyramid of a tile may only be
+    computed once EVERY rank has written its z-range, so rank 0 waits on the group before it starts it.
+    A derivatives folder without ``DarkMaster_cropped.tif`` raises (``load_shadow_correction``); no
+    derivatives folder at all leaves ``darkfield=None``, which the reference cannot correct with either
+    (``flatfield_correction`` dereferences it, ``filtering.py:371-377``) -- ``ValueError`` here.
     """
+    if world_size > 1 and group is None:
+        raise ValueError("destripe_channel with world_size > 1 needs a group to order the pyramid after all ranks")
     from . import pyramid
 
     logger = logger or logging.getLogger("dsx.zarr")
@@ -426,7 +534,7 @@ def destripe_channel(
         flatfield = tif.imread(str(flatfield_path))
         shadow_correction = load_shadow_correction(derivatives_path, output_folder, flatfield, logger)
         if shadow_correction["darkfield"] is None:
-            shadow_correction = None  # no derivatives folder: the reference would fail inside the filter
+            raise ValueError(f"No darkfield for the shading correction: {derivatives_path} does not exist")
         src = tile_path.joinpath(multiscale) if tile_path.joinpath(multiscale, ".zarray").exists() else tile_path
         n, _ = destripe_zarr(
             str(src),
@@ -442,9 +550,13 @@ def destripe_channel(
             compressor=compressor,
             logger=logger,
             tile_name=tile_path.name,
+            group=group,
         )
         done[tile_path.name] = n
-        if rank == 0 and world_size == 1 and n_levels > 1:
+        if group is not None and world_size > 1:
+            group.barrier()  # level 0 of this tile is complete on every rank
+        if rank == 0 and n_levels > 1:
+            dev = int(os.environ.get("LOCAL_RANK", rank)) if device is None else device
             pyramid.compute_multiscale(str(output_folder.joinpath("0")), str(output_folder), n_levels=n_levels,
-                                       chunks=output_chunks, compressor=compressor, device=rank if device is None else device)  # fmt: skip
+                                       chunks=output_chunks, compressor=compressor, device=dev)  # fmt: skip
     return done

@@ -42,6 +42,7 @@ extern "C" {
 #define DSX_ENOMEM (-4)   /* device or host allocation failed                       */
 #define DSX_ELIMIT (-5)   /* plane exceeds an implementation limit                  */
 #define DSX_ECOMM (-6)    /* RCCL error / communicator not initialised              */
+#define DSX_EIO (-7)      /* chunk file could not be read / written                  */
 
 /* plane element types */
 #define DSX_U16 0 /* uint16 pixels (TIFF path, destriper.py:172-200)                 */
@@ -128,6 +129,10 @@ int dsx_memcpy_d2h_async(dsx_ctx* ctx, void* dst, const void* d_src, size_t byte
  * before it has finished (event record + stream wait; nothing blocks the host).                 */
 int dsx_stream_wait(dsx_ctx* ctx, int waiter, int signaller);
 int dsx_stream_sync(dsx_ctx* ctx, int stream_id);
+/* Host-visible completion marks, slots 0..7: record on a stream, later block the host until everything
+ * submitted to that stream before the record has finished (staging buffer k may be refilled / written out). */
+int dsx_event_record(dsx_ctx* ctx, int slot, int stream_id);
+int dsx_event_sync(dsx_ctx* ctx, int slot);
 /* HIP events on the context stream: start, stop -> elapsed milliseconds. */
 int dsx_timer_start(dsx_ctx* ctx);
 int dsx_timer_stop(dsx_ctx* ctx, float* ms);
@@ -153,6 +158,17 @@ int dsx_planes_to_bricks_u16(dsx_ctx* ctx, const void* d_planes, void* d_bricks,
  * cropped), value = floor(sum of 8 / 8): compute_pyramid(), zarr_destriper.py:365-407, i.e.
  * xarray_multiscale.reducers.windowed_mean + preserve_dtype.  Asynchronous on the context stream. */
 int dsx_downsample2_u16(dsx_ctx* ctx, const void* d_src, void* d_dst, int Z, int Y, int X);
+
+/* Host side of the chunk map: n Zarr chunk files <-> memory (normally the pinned staging buffers) on
+ * `threads` native threads -- what zarr / numcodecs do under the reference's worker processes
+ * (zarr_destriper.py:336, 1042-1074).  Raw chunks or zlib streams (zlib_chunks / zlib_level >= 0);
+ * a missing chunk reads as the 16-bit fill value; writes go to "<path>.tmp" and are renamed.
+ * bytes[i] is the decompressed chunk size.  Synchronous; no GPU involved (ctx may be NULL: the
+ * message of a failure is then read with dsx_last_error(NULL)).                                   */
+int dsx_io_read_chunks(dsx_ctx* ctx, const char* const* paths, void* const* dst, const size_t* bytes,
+                       int n, int threads, int zlib_chunks, uint16_t fill_value);
+int dsx_io_write_chunks(dsx_ctx* ctx, const char* const* paths, const void* const* src,
+                        const size_t* bytes, int n, int threads, int zlib_level);
 
 /* flatfield_correction() of one plane as a stand-alone call (filtering.py:338-414): dark subtraction
  * (integer planes truncate, :400-403), division by the flat, baseline, clip, uint16.  dark is

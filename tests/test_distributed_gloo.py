@@ -235,3 +235,79 @@ def test_file_rendezvous_atomic_and_timeout(tmp_path):
     assert not [f for f in os.listdir(str(tmp_path)) if f.startswith(".tmp_")]
     a.cleanup()
     assert not os.path.exists(str(tmp_path)) or not os.listdir(str(tmp_path))
+
+
+# ---- destripe_zarr under two ranks on ONE store (engine replaced by the CPU oracle) ---------------------
+class _RdzvBarrier:
+    def __init__(self, rank, world, directory):
+        from aind_smartspim_destripe_amd.distributed import FileRendezvous
+
+        self.r, self.n = FileRendezvous(rank, world, directory), 0
+
+    def barrier(self):
+        self.n += 1
+        self.r.barrier("b{}".format(self.n))
+
+
+def _oracle_destripe_planes(planes, input_tile_path, no_cells_config, cells_config, shadow_correction=None,
+                            microscope_high_int=2700, out_dtype=np.uint16, **_):
+    from oracle import destripe_oracle as orc
+
+    out = [orc.filter_stripes(p, input_tile_path, no_cells_config, cells_config, shadow_correction, microscope_high_int)
+           for p in planes]  # fmt: skip
+    return np.clip(np.stack(out), 0, 65535).astype(out_dtype)
+
+
+def _zarr_rank_worker(rank, world, src_path, out_path, rdzv_dir, q):
+    sys.path.insert(0, REPO)
+    from aind_smartspim_destripe_amd import filtering as fl
+    from aind_smartspim_destripe_amd import synth, zarr_destriper as zd
+
+    fl.destripe_planes = _oracle_destripe_planes  # no GPU here: the chunk-map logic is what is under test
+    group = _RdzvBarrier(rank, world, rdzv_dir) if world > 1 else None
+    n, _ = zd.destripe_zarr(src_path, out_path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, None,
+                            prediction_chunksize=(4, 48, 64), output_chunks=(1, 1, 4, 16, 16), rank=rank,
+                            world_size=world, device=0, device_retile=False, group=group)  # fmt: skip
+    q.put((rank, n))
+
+
+def test_two_rank_destripe_zarr_matches_single_rank(tmp_path):
+    """Both ranks run destripe_zarr on one store (z-ranges of whole output chunks, rank 0 creates the array
+    anew and atomically, a stale array of another geometry is ignored); the result equals a one-rank run."""
+    import multiprocessing as mp
+
+    from aind_smartspim_destripe_amd import synth
+    from aind_smartspim_destripe_amd.mini_zarr import MiniZarrArray
+
+    vol = np.stack([synth.synthetic_plane(k, 48, 64) for k in range(12)])
+    src = MiniZarrArray.create(str(tmp_path / "in.zarr"), (1, 1, 12, 48, 64), (1, 1, 4, 16, 16), np.uint16)
+    src[0, 0] = vol
+    # stale output of an earlier run with another shape: must not be picked up by the waiting rank
+    MiniZarrArray.create(str(tmp_path / "out2.zarr"), (1, 1, 3, 8, 8), (1, 1, 1, 8, 8), np.uint16)
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world, out in ((1, "out1.zarr"), (2, "out2.zarr")):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_zarr_rank_worker,
+                             args=(r, world, str(tmp_path / "in.zarr"), str(tmp_path / out), str(tmp_path / "rdzv"), q))
+                 for r in range(world)]  # fmt: skip
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=300) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        results[world] = got
+    assert results[1] == [(0, 12)] and results[2] == [(0, 8), (1, 4)]  # 3 output z-chunks: 2 + 1
+    a = MiniZarrArray.open(str(tmp_path / "out1.zarr"))
+    b = MiniZarrArray.open(str(tmp_path / "out2.zarr"))
+    assert a.shape == b.shape == (1, 1, 12, 48, 64)
+    np.testing.assert_array_equal(a[0, 0], b[0, 0])
+    assert a[0, 0].std() > 0
+
+
+def test_destripe_channel_needs_group_for_many_ranks(tmp_path):
+    from aind_smartspim_destripe_amd import zarr_destriper as zd
+
+    with pytest.raises(ValueError):
+        zd.destripe_channel(str(tmp_path), str(tmp_path), "Ex_561_Em_593", str(tmp_path), {}, {}, {}, world_size=2)

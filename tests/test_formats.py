@@ -198,3 +198,43 @@ def test_destripe_zarr_device_retile_equals_host_path(tmp_path, in_chunks):
     raw = np.empty(8 * 32 * 32, np.uint16)
     MiniZarrArray.open(str(tmp_path / "out_1.zarr")).read_chunk_into((0, 0, 2, 0, 0), raw)
     assert raw.reshape(8, 32, 32)[4:].sum() == 0 and raw.reshape(8, 32, 32)[:4].any()
+
+
+def test_native_chunk_io_roundtrip(tmp_path):
+    """dsx_io_read_chunks / dsx_io_write_chunks (native threads, no GPU): raw and zlib chunks agree with the
+    Python store code in both directions, a missing chunk reads as the fill value, a bad path fails loudly."""
+    import ctypes
+
+    from aind_smartspim_destripe_amd import engine as eng_mod
+    from aind_smartspim_destripe_amd.mini_zarr import MiniZarrArray
+
+    lib = eng_mod.load_library()
+
+    def call(fn, paths, arrays, *extra):
+        n = len(paths)
+        cp = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        dp = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
+        nb = (ctypes.c_size_t * n)(*[a.nbytes for a in arrays])
+        return fn(None, cp, dp, nb, n, 4, *extra)
+
+    rs = np.random.RandomState(5)
+    vol = rs.randint(0, 65535, (8, 32, 48)).astype(np.uint16)
+    for comp, level in ((None, -1), ("zlib", 1)):
+        a = MiniZarrArray.create(str(tmp_path / "a_{}".format(comp)), (1, 1, 8, 32, 48), (1, 1, 4, 16, 16), np.uint16,
+                                 compressor=comp)  # fmt: skip
+        idxs = [(0, 0, z, y, x) for z in range(2) for y in range(2) for x in range(3)]
+        bricks = [np.ascontiguousarray(vol[4 * z : 4 * z + 4, 16 * y : 16 * y + 16, 16 * x : 16 * x + 16]) for _, _, z, y, x in idxs]
+        assert call(lib.dsx_io_write_chunks, [a._chunk_path(i) for i in idxs], bricks, level) == 0
+        np.testing.assert_array_equal(a[0, 0], vol)  # the Python reader understands what the native writer wrote
+        b = MiniZarrArray.create(str(tmp_path / "b_{}".format(comp)), (1, 1, 8, 32, 48), (1, 1, 4, 16, 16), np.uint16,
+                                 compressor=comp, fill_value=7)  # fmt: skip
+        b[0, 0, :, :, :32] = vol[:, :, :32]  # chunks x == 2 are never written
+        got = [np.empty((4, 16, 16), np.uint16) for _ in idxs]
+        assert call(lib.dsx_io_read_chunks, [b._chunk_path(i) for i in idxs], got, 0 if comp is None else 1, 7) == 0
+        for (_, _, z, y, x), g in zip(idxs, got):
+            want = vol[4 * z : 4 * z + 4, 16 * y : 16 * y + 16, 16 * x : 16 * x + 16] if x < 2 else np.full((4, 16, 16), 7)
+            np.testing.assert_array_equal(g, want)
+    bad = [np.zeros(8, np.uint16)]
+    open(str(tmp_path / "short"), "wb").write(b"abc")
+    assert call(lib.dsx_io_read_chunks, [str(tmp_path / "short")], bad, 0, 0) == -7
+    assert b"short" in lib.dsx_last_error(None)

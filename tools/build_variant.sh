@@ -2,4 +2,4 @@
 # build an experiment variant of the library next to the product one: tools/build_variant.sh <name> [-DFLAG ...]
 # -> aind_smartspim_destripe_amd/_lib/libdsx_<name>.so (select with DSX_LIB=... ; travels to the GPU box)
 N=$1; shift
-cd "$(dirname "$0")/../aind_smartspim_destripe_amd/csrc" && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC "$@" -o ../_lib/libdsx_$N.so dsx.hip
+cd "$(dirname "$0")/../aind_smartspim_destripe_amd/csrc" && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC "$@" -o ../_lib/libdsx_$N.so dsx.hip -lz -lpthread
