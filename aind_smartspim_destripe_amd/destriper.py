@@ -33,31 +33,40 @@ def _get_extension(path):
     return Path(path).suffix
 
 
-def imsave(path, img, compression=1, output_format: Optional[str] = None):
-    """Save a plane (``destriper.py:49-110``): any readable input format is written as ``<stem>.tiff`` unless
-    ``output_format`` names another supported extension.
+_TIFF_SOURCES = {".raw", ".png", ".tif", ".tiff"}  # inputs whose result is written as <stem>.tiff
 
-    The reference passes ``compressionargs={"level": compression}`` to ``tifffile.imsave`` without a
-    ``compression=`` codec, which writes uncompressed strips; so does this function.
+
+def _write_plane(filename, img, compression):
+    """One writer per output extension.  TIFF: the reference hands ``compressionargs={"level": ...}`` to
+    ``tifffile.imsave`` without naming a codec, which writes uncompressed strips (``destriper.py:82-101``);
+    ``compression`` is accepted and has no effect here either."""
+    ext = Path(filename).suffix
+    if ext in (".tif", ".tiff"):
+        mini_tiff.imwrite(filename, img)
+    elif ext == ".png":
+        raise NotImplementedError("PNG needs imageio, which is not available in this environment")
+    else:  # pragma: no cover - callers only pass supported extensions
+        raise NotImplementedError(ext)
+
+
+def imsave(path, img, compression=1, output_format: Optional[str] = None):
+    """Save a plane next to ``path`` (reference ``destriper.py:49-110``).
+
+    Without ``output_format`` every readable source format is saved as ``<stem>.tiff`` (anything else:
+    ``NotImplementedError``); with it, as ``<stem><output_format>`` for the supported output extensions
+    (anything else: ``ValueError``).
     """
-    extension = _get_extension(path)
-    if output_format is None:
-        if extension in (".raw", ".png", ".tif", ".tiff"):
-            mini_tiff.imwrite(os.path.splitext(path)[0] + ".tiff", img)
-        else:
-            raise NotImplementedError(
-                f"We can't save in {extension} format, available: {SUPPORTED_OUTPUT_EXTENSIONS}"
-            )
-    else:
+    stem = os.path.splitext(path)[0]
+    if output_format is not None:
         if output_format not in SUPPORTED_OUTPUT_EXTENSIONS:
             raise ValueError(
                 f"Output format {output_format} is not valid! Supported extensions are: {SUPPORTED_OUTPUT_EXTENSIONS}"
             )
-        filename = os.path.splitext(path)[0] + output_format
-        if output_format == ".tif" or output_format == ".tiff":
-            mini_tiff.imwrite(filename, img)
-        elif output_format == ".png":
-            raise NotImplementedError("PNG needs imageio, which is not available in this environment")
+        return _write_plane(stem + output_format, img, compression)
+    extension = _get_extension(path)
+    if extension not in _TIFF_SOURCES:
+        raise NotImplementedError(f"We can't save in {extension} format, available: {SUPPORTED_OUTPUT_EXTENSIONS}")
+    return _write_plane(stem + ".tiff", img, compression)
 
 
 def _log_unreadable(output_dir, input_path):
@@ -133,21 +142,39 @@ def _read_filter_save(input_dict: dict):
 
 
 def _find_all_images(search_path: PathLike, input_path: PathLike, output_path: PathLike):
-    """All readable images below ``search_path``; mirrors the folder tree under ``output_path``
-    (``destriper.py:230-264``)."""
-    input_path, output_path, search_path = Path(input_path), Path(output_path), Path(search_path)
-    assert search_path.is_dir()
-    img_paths = []
-    for p in search_path.iterdir():
-        if p.is_file():
-            if p.suffix in SUPPORTED_READING_EXTENSIONS:
-                img_paths.append(p)
-        elif p.is_dir():
-            o = output_path.joinpath(p.relative_to(input_path))
-            if not o.exists():
-                o.mkdir(parents=True)
-            img_paths.extend(_find_all_images(p, input_path, output_path))
-    return img_paths
+    """Readable images below ``search_path``, depth first in directory order; every sub-folder met on the way is
+    re-created under ``output_path`` at the same position relative to ``input_path`` (reference
+    ``destriper.py:230-264``)."""
+    root_in, root_out, here = Path(input_path), Path(output_path), Path(search_path)
+    assert here.is_dir()
+    found = []
+    for entry in here.iterdir():
+        if entry.is_dir():
+            root_out.joinpath(entry.relative_to(root_in)).mkdir(parents=True, exist_ok=True)
+            found += _find_all_images(entry, root_in, root_out)
+        elif entry.is_file() and entry.suffix in SUPPORTED_READING_EXTENSIONS:
+            found.append(entry)
+    return found
+
+
+def _prepare_tree(input_path, output_path):
+    """What ``batch_filter`` does before it filters (reference ``destriper.py:322-364``): forget the error log of
+    an earlier run, collect the images (mirroring the folder tree), copy the acquisition's ``.txt`` / ``.ini``
+    side files, and pair every image with its output path."""
+    src_root, dst_root = Path(input_path), Path(output_path)
+    stale_log = dst_root / "destripe_log.txt"
+    if stale_log.exists():
+        stale_log.unlink()
+    logger.info(f"Looking for images in {src_root}")
+    images = _find_all_images(src_root, src_root, dst_root)
+    logger.info(f"Found {len(images)} compatible images")
+    for side_file in src_root.iterdir():
+        if side_file.suffix in (".txt", ".ini"):
+            shutil.copyfile(side_file, dst_root / side_file.name)
+    targets = [dst_root / img.relative_to(src_root) for img in images]
+    for t in targets:
+        t.parent.mkdir(parents=True, exist_ok=True)
+    return images, targets
 
 
 def batch_filter(
@@ -169,20 +196,7 @@ def batch_filter(
     """
     input_path, output_path = Path(input_path), Path(output_path)
     error_path = os.path.join(output_path, "destripe_log.txt")
-    if os.path.exists(error_path):
-        os.remove(error_path)
-    logger.info(f"Looking for images in {input_path}")
-    img_paths = _find_all_images(input_path, input_path, output_path)
-    logger.info(f"Found {len(img_paths)} compatible images")
-    for file in input_path.iterdir():  # copy text and ini files (:340-343)
-        if Path(file).suffix in [".txt", ".ini"]:
-            shutil.copyfile(file, os.path.join(output_path, os.path.split(file)[1]))
-    outs = []
-    for p in img_paths:
-        o = output_path.joinpath(p.relative_to(input_path))
-        if not o.parent.exists():
-            o.parent.mkdir(parents=True)
-        outs.append(o)
+    img_paths, outs = _prepare_tree(input_path, output_path)
     batch = max(1, int(chunks))
     written = 0
     with ThreadPoolExecutor(max_workers=max(1, int(workers))) as pool:

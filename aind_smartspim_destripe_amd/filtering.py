@@ -17,6 +17,7 @@ Same names, argument meaning and error behaviour as the reference
   filter never calls them (the engine builds its own gain tables).
 """
 
+import collections
 import math
 import warnings
 from typing import List, Optional, Tuple
@@ -174,7 +175,7 @@ def flatfield_correction(image_tiles, flatfield, darkfield, baseline=None, devic
 # ---------------------------------------------------------------------------------------------
 # GPU hot path
 # ---------------------------------------------------------------------------------------------
-_ENGINES = {}
+_ENGINES = collections.OrderedDict()
 _MAX_CACHED_PLANS = 8
 
 
@@ -211,21 +212,29 @@ def get_engine(shape, cells_config, no_cells_config, microscope_high_int=2700, f
     """Planned engine for a plane geometry + config pair (cached per process and device)."""
     shade_key = None
     if flatfield is not None:
-        shade_key = (id(flatfield), id(darkfield), np.shape(flatfield), np.shape(darkfield))
+        # keyed on the memory the planes occupy, not on the Python object: ``flatfields[brain_side]`` makes a new
+        # view object per call (prospective flats, filtering.py:478), which would miss the cache every time
+        shade_key = (_array_key(flatfield), _array_key(darkfield))
     key = (device, tuple(shape), _cfg_key(cells_config), _cfg_key(no_cells_config),
            float(microscope_high_int), shade_key, int(max_batch))  # fmt: skip
     eng = _ENGINES.get(key)
-    if eng is None:
-        if len(_ENGINES) >= _MAX_CACHED_PLANS:
-            _, old = _ENGINES.popitem()
-            old[0].close()
-        e = _engine.DestripeEngine(device)
-        e.plan(shape[0], shape[1], cells_config, no_cells_config, microscope_high_int, max_batch,
-               flatfield, darkfield)  # fmt: skip
-        # keep the shading arrays alive so that id() stays unique while the plan is cached
-        eng = (e, flatfield, darkfield)
-        _ENGINES[key] = eng
-    return eng[0]
+    if eng is not None:
+        _ENGINES.move_to_end(key)  # least recently used entries go first
+        return eng[0]
+    while len(_ENGINES) >= _MAX_CACHED_PLANS:
+        _, old = _ENGINES.popitem(last=False)
+        old[0].close()
+    e = _engine.DestripeEngine(device)
+    e.plan(shape[0], shape[1], cells_config, no_cells_config, microscope_high_int, max_batch,
+           flatfield, darkfield)  # fmt: skip
+    # the shading arrays stay referenced, so their addresses stay unique while the plan is cached
+    _ENGINES[key] = (e, flatfield, darkfield)
+    return e
+
+
+def _array_key(a):
+    a = np.asarray(a)
+    return (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str)
 
 
 def _as_plane_dtype(image):
