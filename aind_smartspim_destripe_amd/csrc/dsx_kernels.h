@@ -653,6 +653,9 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
 
 // IN_KIND: 0 = uint16 pixels (log + statistic fused), 1 = float32 pixels (same), 2 = float32 aa_{l-1}
 // DSX_FWD_BOUNDS / DSX_INV_BOUNDS: build-time experiment hooks (tools/build_variant.sh), e.g. -DDSX_FWD_BOUNDS=256,4
+#ifndef DSX_MEDIAN_BALLOT
+#define DSX_MEDIAN_BALLOT 1
+#endif
 #ifndef DSX_FWD_BOUNDS
 #define DSX_FWD_BOUNDS 256
 #endif
@@ -1231,145 +1234,139 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   __syncthreads();  // the only block-wide barrier: afterwards every wave works on its own rows
   if (!live) return;
 
-  // Order-preserving 32-bit keys, split into packed 16-bit halves {row a | row b << 16}:
-  // hs = high halves, ls = low halves, both in signed order (^ 0x8000) for the saturating compare.
-  unsigned hs[E], ls[E];
+  // Background values (masked entries zeroed, filtering.py:195-197) stay in registers as floats; slots past
+  // the row end hold +inf (never below a threshold, never a minimum).
+  float va[E], vb[E];
   mask_t maska = 0, maskb = 0;
-  auto make_keys = [&](int e, float va, float vb, bool valid) {
-    unsigned ka = 0xFFFFFFFFu, kb = 0xFFFFFFFFu;  // padding sorts last
-    if (valid) {
-      const bool ma = fabsf(va) > thr, mb = fabsf(vb) > thr;
-      if (ma) maska |= ((mask_t)1 << e);
-      if (mb) maskb |= ((mask_t)1 << e);
-      ka = f32_key(ma ? 0.f : va);
-      kb = f32_key(mb ? 0.f : vb);
-    }
-    hs[e] = ((ka >> 16) | (kb & 0xFFFF0000u)) ^ 0x80008000u;
-    ls[e] = ((ka & 0xFFFFu) | (kb << 16)) ^ 0x80008000u;
+  auto take = [&](int e, float xa, float xb, bool valid) {
+    const bool ma = valid && fabsf(xa) > thr, mb = valid && fabsf(xb) > thr;
+    if (ma) maska |= ((mask_t)1 << e);
+    if (mb) maskb |= ((mask_t)1 << e);
+    va[e] = valid ? (ma ? 0.f : xa) : __builtin_huge_valf();
+    vb[e] = valid ? (mb ? 0.f : xb) : __builtin_huge_valf();
   };
 #pragma unroll
   for (int g = 0; g < GV; ++g) {
     if (g < gf) {
-      make_keys(4 * g + 0, ra4[g].x, rb4[g].x, true);
-      make_keys(4 * g + 1, ra4[g].y, rb4[g].y, true);
-      make_keys(4 * g + 2, ra4[g].z, rb4[g].z, true);
-      make_keys(4 * g + 3, ra4[g].w, rb4[g].w, true);
+      take(4 * g + 0, ra4[g].x, rb4[g].x, true);
+      take(4 * g + 1, ra4[g].y, rb4[g].y, true);
+      take(4 * g + 2, ra4[g].z, rb4[g].z, true);
+      take(4 * g + 3, ra4[g].w, rb4[g].w, true);
     }
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    if (k < nt) make_keys(4 * GV + k, rta[k], rtb[k], tn + 64 * k < N);
+    if (k < nt) take(4 * GV + k, rta[k], rtb[k], tn + 64 * k < N);
+  }
+  if (!has_b) {  // odd row count: the partner row is all zeros
+    for_slots<GV>(gf, nt, [&](int e) { if (vb[e] != __builtin_huge_valf()) vb[e] = 0.f; });
   }
 
   // ---- exact row medians (np.median, filtering.py:201) ------------------------------------------
-  // k-th smallest key by bisection, 16 bits at a time: first the high half over all elements, then
-  // the low half over the elements that share the selected high half.
+  // k-th smallest by bracketing in the VALUE domain: C(t) = #{x < t} is one compare + one add per value
+  // and row; [lo, hi) with C(lo) <= k < C(hi) shrinks by regula falsi on (value, count) alternating with
+  // the midpoint of the order-preserving integer keys (which bounds the number of steps), until exactly
+  // one element -- or one value, for ties -- is left; the answer is then min{x >= lo}.  The zero spike
+  // of the masked entries is probed first (C(0) and #{x <= 0}).  Both rows run in lockstep; everything
+  // but the per-value compares is wave-uniform.  (Round 1 selected on packed 16-bit key halves by 16-step
+  // bisection plus a bucket walk: ~2.1 k vector instructions per row pair with the key packing and
+  // unpacking around it; this takes ~0.9 k.)
   float meda = 0.f, medb = 0.f;
   // the medians only enter through the masked positions: skip them for a mask-free pair of rows
   const bool any_mask = __ballot((maska | maskb) != (mask_t)0) != 0ull;
   if (any_mask && !(a.ablate & 1)) {
-  const unsigned k1 = (unsigned)(N - 1) >> 1;
-  const unsigned rhi = bisect_pk16<GV, E>(hs, k1, k1, gf, nt);
-  unsigned below = __reduce_add_sync(~0ull, count_below_pk16<GV, E>(hs, rhi ^ 0x80008000u, gf, nt));
-  // Low halves of the candidates (elements whose high half equals the selected one), in unsigned
-  // order; all other elements get the maximum 0xFFFF.
-  unsigned lsel[E];
-  {
-    const dsx_s16x2 rv = as_s16x2(rhi ^ 0x80008000u);
-    for_slots<GV>(gf, nt, [&](int e) {
-      const dsx_s16x2 eq = (as_s16x2(hs[e]) == rv);  // -1 where the high half matches
-      lsel[e] = ((ls[e] ^ 0x80008000u) & as_u32(eq)) | ~as_u32(eq);
-    });
-  }
-  // Rank inside the bucket.  The bucket is usually tiny (a 2^-7 relative slice of the value range),
-  // so walk its distinct values in ascending order: next value = lower bound + wave-min of the
-  // wrapped differences; stop when the multiplicities passed exceed the rank.  Bounded number of
-  // rounds; anything left falls back to the 16-step bisection of the low half.
-  // (The loop state is wave-uniform, but mixing SGPR- and VGPR-resident values across the loop
-  // crashes ROCm 7.2's "SI Fix SGPR copies"; a VGPR zero makes all of it vector state.)
-  unsigned vz;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-  unsigned rank_a = (k1 - (below & 0xFFFFu)) | vz, rank_b = (k1 - (below >> 16)) | vz;
-  unsigned lb = vz, rlo = vz;
-  unsigned done_a = vz, done_b = vz;
-  for (int round = 0; round < ((a.ablate & 8) ? 0 : 12) && !(done_a & done_b); ++round) {
-    typedef unsigned short dsx_u16x2 __attribute__((ext_vector_type(2)));
-    union U { unsigned u; dsx_u16x2 v; };
-    U lbv; lbv.u = lb;
-    U mn; mn.u = 0xFFFFFFFFu;
-    for_slots<GV>(gf, nt, [&](int e) {
-      U x; x.u = lsel[e];
-      U d; d.v = x.v - lbv.v;  // elements below the bound wrap around to large values
-      mn.v = __builtin_elementwise_min(mn.v, d.v);
-    });
+    const unsigned k1 = (unsigned)(N - 1) >> 1;
+    const bool even = (N & 1) == 0;
+    auto count2 = [&](float ta, float tb, bool le) -> unsigned {  // (#a < ta) | (#b < tb) << 16, wave totals
+#if DSX_MEDIAN_BALLOT
+      // one vector compare per value; the wave total is a scalar population count of the compare mask
+      unsigned ca = 0, cb = 0;
+      for_slots<GV>(gf, nt, [&](int e) {
+        ca += (unsigned)__popcll(__ballot(le ? (va[e] <= ta) : (va[e] < ta)));
+        cb += (unsigned)__popcll(__ballot(le ? (vb[e] <= tb) : (vb[e] < tb)));
+      });
+      return ca | (cb << 16);
+#else
+      unsigned ca = 0, cb = 0;
+      for_slots<GV>(gf, nt, [&](int e) {
+        ca += (le ? (va[e] <= ta) : (va[e] < ta)) ? 1u : 0u;
+        cb += (le ? (vb[e] <= tb) : (vb[e] < tb)) ? 1u : 0u;
+      });
+      return (unsigned)__builtin_amdgcn_readfirstlane((int)__reduce_add_sync(~0ull, ca | (cb << 16)));
+#endif
+    };
+    // bracket state per row r (0 = a, 1 = b), wave-uniform
+    float lo[2], hi[2];
+    unsigned clo[2], chi[2];
+    bool done[2];
+    int same[2] = {0, 0}, last[2] = {0, 0};  // consecutive updates of one end: regula falsi is stalling
+    const float thr_up = as_f32(as_u32(thr) + 1u);  // next float above thr (thr >= 0): C(thr_up) = N
+    {
+      const unsigned c0 = count2(0.f, 0.f, false), c0e = count2(0.f, 0.f, true);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      U t; t.u = (unsigned)__shfl_xor((int)mn.u, o);
-      mn.v = __builtin_elementwise_min(mn.v, t.v);
+      for (int r = 0; r < 2; ++r) {
+        const unsigned lt = r ? (c0 >> 16) : (c0 & 0xFFFFu), le = r ? (c0e >> 16) : (c0e & 0xFFFFu);
+        done[r] = false;
+        if (k1 < lt) {            // the statistic is negative
+          lo[r] = -thr; clo[r] = 0u; hi[r] = 0.f; chi[r] = lt;
+        } else if (k1 < le) {     // inside the zero spike: [0, denorm_min) holds the value 0 only
+          lo[r] = 0.f; clo[r] = lt; hi[r] = as_f32(1u); chi[r] = le; done[r] = true;
+        } else {                  // positive: C(denorm_min) = #{x <= 0}
+          lo[r] = as_f32(1u); clo[r] = le; hi[r] = thr_up; chi[r] = (unsigned)N;
+        }
+      }
     }
-    U val; val.v = lbv.v + mn.v;  // smallest remaining value per row
-    // multiplicity of that value: count zero differences
-    U cnt; cnt.u = 0;
-    const dsx_u16x2 one = {1, 1};
+    for (int it = 0; it < 200 && !(done[0] && done[1]); ++it) {
+      float t[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const unsigned kl = f32_key(lo[r]), kh = f32_key(hi[r]);
+        if (!done[r] && (chi[r] - clo[r] <= 1u || kh - kl <= 1u)) done[r] = true;
+        // regula falsi aims at rank k + 1/2; when it stalls (three updates of the same end in a row), on every
+        // fourth step, and whenever it leaves the bracket, the midpoint of the integer keys halves the number
+        // of representable values left (at most 4 x 32 steps in all)
+        const float frac = ((float)(k1 - clo[r]) + 0.5f) / (float)(chi[r] - clo[r]);
+        float tt = lo[r] + (hi[r] - lo[r]) * frac;
+        const float tm = key_f32(kl + ((kh - kl) >> 1));
+        if (same[r] >= 3 || (it & 3) == 3 || !(tt > lo[r] && tt < hi[r])) { tt = tm; same[r] = 0; }
+        t[r] = done[r] ? lo[r] : tt;
+      }
+      if (done[0] && done[1]) break;
+      const unsigned c = count2(t[0], t[1], false);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const unsigned cr = r ? (c >> 16) : (c & 0xFFFFu);
+        if (!done[r]) {
+          const int side = (cr <= k1) ? 1 : 2;
+          if (side == 1) { lo[r] = t[r]; clo[r] = cr; }
+          else { hi[r] = t[r]; chi[r] = cr; }
+          same[r] = (side == last[r]) ? same[r] + 1 : 1;
+          last[r] = side;
+        }
+      }
+    }
+    // s_k = min{x >= lo};  even N: s_{k+1} = s_k if more than k + 1 values lie below hi, else min{x >= hi}
+    float m_lo[2] = {__builtin_huge_valf(), __builtin_huge_valf()}, m_hi[2] = {__builtin_huge_valf(), __builtin_huge_valf()};
     for_slots<GV>(gf, nt, [&](int e) {
-      U x; x.u = lsel[e];
-      U z; z.v = x.v - val.v;
-      cnt.v += one - __builtin_elementwise_min(z.v, one);
+      m_lo[0] = fminf(m_lo[0], va[e] >= lo[0] ? va[e] : __builtin_huge_valf());
+      m_lo[1] = fminf(m_lo[1], vb[e] >= lo[1] ? vb[e] : __builtin_huge_valf());
+      if (even) {
+        m_hi[0] = fminf(m_hi[0], va[e] >= hi[0] ? va[e] : __builtin_huge_valf());
+        m_hi[1] = fminf(m_hi[1], vb[e] >= hi[1] ? vb[e] : __builtin_huge_valf());
+      }
     });
-    const unsigned c = __reduce_add_sync(~0ull, cnt.u);
-    const unsigned va = val.u & 0xFFFFu, vb = val.u >> 16;
-    if (!done_a) {
-      if (rank_a < (c & 0xFFFFu) || va == 0xFFFFu) { rlo = (rlo & 0xFFFF0000u) | va; done_a = 1u; }
-      else { rank_a -= (c & 0xFFFFu); lb = (lb & 0xFFFF0000u) | (va + 1u); }
+    float sk[2], sk1[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      sk[r] = wave_min_f32(m_lo[r]);
+      sk1[r] = sk[r];
+      if (even) {
+        const float nxt = wave_min_f32(m_hi[r]);
+        sk1[r] = (k1 + 1u < chi[r]) ? sk[r] : nxt;
+      }
     }
-    if (!done_b) {
-      if (rank_b < (c >> 16) || vb == 0xFFFFu) { rlo = (rlo & 0xFFFFu) | (vb << 16); done_b = 1u; }
-      else { rank_b -= (c >> 16); lb = (lb & 0xFFFFu) | ((vb + 1u) << 16); }
-    }
-  }
-  // the state is uniform: read it back into scalars for the (wave-uniform) fallback decision
-  const bool all_done = (__builtin_amdgcn_readfirstlane(done_a & done_b) != 0);
-  rlo = __builtin_amdgcn_readfirstlane(rlo);
-  if (!all_done) {
-    // dense bucket: bisection of the low half (signed-order operands, sentinel never counted)
-    unsigned lsg[E];
-    for_slots<GV>(gf, nt, [&](int e) { lsg[e] = lsel[e] ^ 0x80008000u; });
-    const unsigned r2 = bisect_pk16<GV, E>(lsg, k1 - (below & 0xFFFFu), k1 - (below >> 16), gf, nt);
-    if (!__builtin_amdgcn_readfirstlane(done_a)) rlo = (rlo & 0xFFFF0000u) | (r2 & 0xFFFFu);
-    if (!__builtin_amdgcn_readfirstlane(done_b)) rlo = (rlo & 0xFFFFu) | (r2 & 0xFFFF0000u);
-  }
-  const unsigned keya = ((rhi & 0xFFFFu) << 16) | (rlo & 0xFFFFu);
-  const unsigned keyb = (rhi & 0xFFFF0000u) | (rlo >> 16);
-  meda = key_f32(keya);
-  medb = key_f32(keyb);
-  if ((N & 1) == 0) {
-    // second middle order statistic: the smallest key above the first one unless the first is tied
-    unsigned c = 0, mna = 0xFFFFFFFFu, mnb = 0xFFFFFFFFu;
-    for_slots<GV>(gf, nt, [&](int e) {
-      const unsigned h = hs[e] ^ 0x80008000u, l = ls[e] ^ 0x80008000u;
-      const unsigned ka = (h << 16) | (l & 0xFFFFu);
-      const unsigned kb = (h & 0xFFFF0000u) | (l >> 16);
-      c += (ka <= keya) ? 1u : 0u;
-      c += (kb <= keyb) ? 0x10000u : 0u;
-      if (ka > keya) mna = min(mna, ka);
-      if (kb > keyb) mnb = min(mnb, kb);
-    });
-    c = __reduce_add_sync(~0ull, c);
-    // cross-lane minimum through an LDS atomic (once per row pair); the row buffer is still unused
-    unsigned* s_mn = (unsigned*)buf;
-    if (lane == 0) { s_mn[0] = 0xFFFFFFFFu; s_mn[1] = 0xFFFFFFFFu; }
-    wave_sync();
-    atomicMin(&s_mn[0], mna);
-    atomicMin(&s_mn[1], mnb);
-    wave_sync();
-    mna = s_mn[0];
-    mnb = s_mn[1];
-    wave_sync();
-    const float v2a = ((c & 0xFFFFu) > k1 + 1) ? meda : key_f32(mna);
-    const float v2b = ((c >> 16) > k1 + 1) ? medb : key_f32(mnb);
-    meda = 0.5f * (meda + v2a);
-    medb = 0.5f * (medb + v2b);
-  }
+    meda = even ? 0.5f * (sk[0] + sk1[0]) : sk[0];
+    medb = even ? 0.5f * (sk[1] + sk1[1]) : sk[1];
   }  // any_mask
   // The medians are wave-uniform (SGPR); ROCm 7.2's instruction selection crashes when they flow
   // into the selects / LDS stores below, so pin them into VGPRs.
@@ -1379,9 +1376,8 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   for_slots<GV>(gf, nt, [&](int e) {
     const int n = (e < 4 * GV) ? 256 * (e >> 2) + 4 * lane + (e & 3) : tn + 64 * (e - 4 * GV);
     if (e < 4 * GV || n < N) {
-      const unsigned h = hs[e] ^ 0x80008000u, l = ls[e] ^ 0x80008000u;
-      const float xa = ((maska >> e) & (mask_t)1) ? meda : key_f32((h << 16) | (l & 0xFFFFu));
-      const float xb = ((maskb >> e) & (mask_t)1) ? medb : key_f32((h & 0xFFFF0000u) | (l >> 16));
+      const float xa = ((maska >> e) & (mask_t)1) ? meda : va[e];
+      const float xb = ((maskb >> e) & (mask_t)1) ? medb : vb[e];
       const float2 z = make_float2(xa, xb);
       buf[K + n] = z;
       if (halo) {
