@@ -513,3 +513,41 @@ def test_width_sweep(engine, golden_sweep):
             check_plane(out, x, delta, key, cfg, lambda size: 6, ref=g[key + "__sample"], stages=stages[::-1], pos=(yy, xx))
     print("[parity] width sweep: {} of {} cases follow the float64 regime's Otsu bin".format(other, 2 * len(g["widths"])))
     assert other <= 8, other
+
+
+@pytest.mark.parametrize(
+    "shape",
+    [
+        (101, 104), (75, 260), (130, 132), (37, 64), (36, 1000), (33, 244), (34, 248), (250, 252), (48, 488),
+        (49, 492), (200, 976), (64, 128), (1026, 36), (40, 2044), (95, 1020),
+    ],
+)
+def test_fused_kernel_edge_shapes(engine, shape):
+    """Planes that take the fused level-1 + 2 kernels (width a multiple of 4) with awkward geometry: odd heights,
+    level-2 widths around the 61-column strips of a wave (one strip, a shifted last strip that overlaps
+    the one before it, a last strip of a single column), level-1 widths around 122 / 126, tiny and tall
+    planes.  Every pixel against the oracle (explained-outlier statement of tests/parity_util.py)."""
+    planes = np.stack([synth.synthetic_plane(k, *shape) for k in (0, 1)])
+    deltas = gpu_deltas(engine, planes)
+    out, cfg = filtering.destripe_planes(
+        planes, "X_0_Y_0", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT,
+        out_dtype=np.float32, return_config=True, max_batch=2,
+    )  # fmt: skip
+    for k in range(2):
+        which, _, _, ref, stages = oracle_plane(planes[k])
+        assert int(cfg[k]) == which
+        assert out[k].shape == ref.shape
+        _check_plane(out[k], planes[k], deltas[k], (shape, k), ref=ref, stages=stages)
+    # per-level cH of plane 0 (forward kernels alone), float32 round-off
+    engine.plan(shape[0], shape[1], synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT, max_batch=2)
+    engine.set_stop_after(1)
+    try:
+        engine.run(planes, out_dtype=np.float32)
+        _, _, _, _, stages = oracle_plane(planes[0])
+        for lv, st in enumerate(stages):
+            ch = engine.level_array(0, lv, eng_mod.STAGE_DETAIL)
+            assert ch.shape == st["ch"].shape
+            scale = max(1.0, np.abs(st["ch"]).max())
+            assert np.abs(ch - st["ch"]).max() <= 2e-5 * scale * (2**lv), (shape, lv)
+    finally:
+        engine.set_stop_after(0)
