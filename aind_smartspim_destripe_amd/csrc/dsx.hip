@@ -38,7 +38,7 @@ struct ProfRec {
 
 struct dsx_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream_ = nullptr;  // the context ("compute") stream; entry points reach it through use_main()
   std::string err;
   bool planned = false;
   dsx::Plan plan;
@@ -84,6 +84,16 @@ struct dsx_ctx {
   int n_streams = 4;
   hipStream_t aux[kMaxStreams] = {};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {};
+  // Cross-call pipelining of the sub-cohort streams: the joins of a split cohort are deferred until something
+  // else needs the context stream, so that an identical run_device call that follows (the next batch of a
+  // steady stream of batches) starts each part right behind the same part of the call before it.
+  int joins_pending = 0;              // parts (incl. part 0) of a split cohort the context stream has not joined yet
+  unsigned long long main_ops = 0;    // operations entry points put on the context stream (use_main calls)
+  struct {
+    const void* in = nullptr; void* out = nullptr; const void* cfg = nullptr;
+    int n = 0, in_dtype = 0, out_dtype = 0, parts = 0;
+    unsigned long long main_ops = 0;
+  } last_split;
   // multi-GPU: RCCL communicator of the one collective of the path (dsx_comm_*)
   void* rccl = nullptr;  // dlopen handle of librccl.so
   ncclComm_t comm = nullptr;
@@ -119,6 +129,15 @@ int fail(dsx_ctx* c, int code, const std::string& msg) {
   return code;
 }
 
+// The context stream for an entry point: first waits for the sub-cohort streams of a split cohort that is
+// still running (deferred joins), and notes that the stream has been used.
+hipStream_t use_main(dsx_ctx* c) {
+  for (int i = 1; i < c->joins_pending; ++i) (void)hipStreamWaitEvent(c->stream_, c->ev_join[i], 0);
+  c->joins_pending = 0;
+  ++c->main_ops;
+  return c->stream_;
+}
+
 #define DSX_HIP(call)                                                                    \
   do {                                                                                   \
     hipError_t e_ = (call);                                                              \
@@ -152,12 +171,12 @@ struct LaunchScope {
       r.cls = cls;
       (void)hipEventCreate(&r.e0);
       (void)hipEventCreate(&r.e1);
-      (void)hipEventRecord(r.e0, c->stream);
+      (void)hipEventRecord(r.e0, c->stream_);
     }
   }
   ~LaunchScope() {
     if (on) {
-      (void)hipEventRecord(r.e1, c->stream);
+      (void)hipEventRecord(r.e1, c->stream_);
       c->prof.push_back(r);
     }
   }
@@ -475,27 +494,49 @@ CohortView make_view(dsx_ctx* ctx, int po, hipStream_t stream) {
 }
 
 // One cohort (<= max_batch planes), split into parts on the context's streams.
+//
+// Part 0 runs on the context stream, parts 1.. on the auxiliary streams behind a fork event.  The context
+// stream does NOT wait for the other parts here: use_main() does that when an entry point needs the stream
+// next.  If the call that follows is another split cohort with the same planes pointer, result pointer,
+// count and element types (and nothing has been put on the context stream in between), every part is
+// simply queued behind the same part of this call -- it reads the input nobody writes and rewrites its
+// own slice of the workspace, control block and result -- so consecutive batches overlap instead of
+// draining the chip at every call boundary.  Anything else joins first, then forks again.
 int run_cohort_split(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out, int out_dtype,
                      int32_t* d_cfg_used, size_t in_plane, size_t out_plane) {
   int parts = ctx->n_streams;
   if (ctx->profiling || ctx->stop_after != 0) parts = 1;
   while (parts > 1 && nb / parts < 16) --parts;  // keep every part big enough to fill the chip
-  if (parts <= 1) return run_cohort(ctx, make_view(ctx, 0, ctx->stream), d_in, in_dtype, nb, d_out, out_dtype, d_cfg_used);
-  DSX_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+  if (parts <= 1) {
+    hipStream_t main = use_main(ctx);  // joins whatever split cohort is still running
+    return run_cohort(ctx, make_view(ctx, 0, main), d_in, in_dtype, nb, d_out, out_dtype, d_cfg_used);
+  }
+  static const bool no_pipe = getenv("DSX_NO_PIPELINE") && atoi(getenv("DSX_NO_PIPELINE")) != 0;
+  auto& ls = ctx->last_split;
+  const bool in_out_disjoint = (const char*)d_in + nb * in_plane <= (const char*)d_out ||
+                               (const char*)d_out + nb * out_plane <= (const char*)d_in;
+  const bool same_call = !no_pipe && ctx->joins_pending == parts && ls.in == d_in && ls.out == d_out && ls.n == nb &&
+                         ls.in_dtype == in_dtype && ls.out_dtype == out_dtype && ls.parts == parts &&
+                         ls.cfg == (const void*)d_cfg_used && ls.main_ops == ctx->main_ops && in_out_disjoint;
+  if (!same_call) {
+    hipStream_t main = use_main(ctx);
+    DSX_HIP(hipEventRecord(ctx->ev_fork, main));
+  }
   const int per = (nb + parts - 1) / parts;
   for (int i = 0; i < parts; ++i) {
     const int po = i * per, n = std::min(per, nb - po);
     if (n <= 0) break;
-    hipStream_t st = (i == 0) ? ctx->stream : ctx->aux[i];
-    if (i > 0) DSX_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
+    hipStream_t st = (i == 0) ? ctx->stream_ : ctx->aux[i];
+    if (i > 0 && !same_call) DSX_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
     const int rc = run_cohort(ctx, make_view(ctx, po, st), (const char*)d_in + po * in_plane, in_dtype, n,
                               (char*)d_out + po * out_plane, out_dtype, d_cfg_used ? d_cfg_used + po : nullptr);
     if (rc != DSX_OK) return rc;
-    if (i > 0) {
-      DSX_HIP(hipEventRecord(ctx->ev_join[i], st));
-      DSX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0));
-    }
+    if (i > 0) DSX_HIP(hipEventRecord(ctx->ev_join[i], st));
   }
+  ctx->joins_pending = parts;
+  ls.in = d_in; ls.out = d_out; ls.cfg = d_cfg_used;
+  ls.n = nb; ls.in_dtype = in_dtype; ls.out_dtype = out_dtype; ls.parts = parts;
+  ls.main_ops = ctx->main_ops;
   return DSX_OK;
 }
 
@@ -527,7 +568,7 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
   c->device = device;
   if (const char* ab = getenv("DSX_ABLATE")) c->ablate = atoi(ab);
   if (const char* ns = getenv("DSX_STREAMS")) c->n_streams = std::max(1, std::min(atoi(ns), (int)dsx_ctx::kMaxStreams));
-  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  e = hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking);
   for (int i = 1; i < dsx_ctx::kMaxStreams && e == hipSuccess; ++i) {
     e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
@@ -551,7 +592,7 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
 void dsx_destroy(dsx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(use_main(ctx));
   (void)dsx_comm_destroy(ctx);
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   free_plan_buffers(ctx);
@@ -567,7 +608,7 @@ void dsx_destroy(dsx_ctx* ctx) {
   if (ctx->ev_xs) (void)hipEventDestroy(ctx->ev_xs);
   for (int i = 0; i < dsx_ctx::kEventSlots; ++i)
     if (ctx->ev_slot[i]) (void)hipEventDestroy(ctx->ev_slot[i]);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream_) (void)hipStreamDestroy(ctx->stream_);
   delete ctx;
 }
 
@@ -580,7 +621,7 @@ int dsx_plan(dsx_ctx* ctx, int height, int width, int max_batch, const dsx_cfg* 
   if ((flat == nullptr) != (dark == nullptr))
     return fail(ctx, DSX_EINVAL, "flatfield and darkfield must be given together");
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   free_plan_buffers(ctx);
 
   const dsx_cfg* src[2] = {no_cells_config, cells_config};  // index 1 == cells_config
@@ -652,7 +693,7 @@ int dsx_set_shading_device(dsx_ctx* ctx, const float* d_flat, const float* d_dar
   if (d_flat && (dark_h < ctx->plan.Hout || dark_w < ctx->plan.Wout))
     return fail(ctx, DSX_EINVAL, "Please, check the shape of the darkfield.");
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   if (ctx->own_shading) { (void)hipFree(ctx->d_flat); (void)hipFree(ctx->d_dark); }
   ctx->own_shading = false;
   ctx->d_flat = const_cast<float*>(d_flat);
@@ -713,7 +754,7 @@ int dsx_run_device(dsx_ctx* ctx, const void* d_in, int in_dtype, int n, void* d_
 int dsx_sync(dsx_ctx* ctx) {
   if (!ctx) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   return DSX_OK;
 }
 
@@ -746,17 +787,17 @@ int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, i
   for (int start = 0; start < n; start += B) {
     const int nb = std::min(B, n - start);
     DSX_HIP(hipMemcpyAsync(ctx->d_stage_in, (const char*)in + start * in_plane, in_plane * nb,
-                           hipMemcpyHostToDevice, ctx->stream));
+                           hipMemcpyHostToDevice, use_main(ctx)));
     const int rc = run_cohort_split(ctx, ctx->d_stage_in, in_dtype, nb, ctx->d_stage_out, out_dtype, d_cfg,
                                     in_plane, out_plane);
     if (rc != DSX_OK) return rc;
     ctx->last_n = nb;
     if (ctx->stop_after == 0)
       DSX_HIP(hipMemcpyAsync((char*)out + start * out_plane, ctx->d_stage_out, out_plane * nb,
-                             hipMemcpyDeviceToHost, ctx->stream));
+                             hipMemcpyDeviceToHost, use_main(ctx)));
     if (cfg_used)
-      DSX_HIP(hipMemcpyAsync(cfg_used + start, d_cfg, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, ctx->stream));
-    DSX_HIP(hipStreamSynchronize(ctx->stream));
+      DSX_HIP(hipMemcpyAsync(cfg_used + start, d_cfg, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, use_main(ctx)));
+    DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   }
   return DSX_OK;
 }
@@ -772,28 +813,28 @@ int dsx_malloc(dsx_ctx* ctx, size_t bytes, void** d_ptr) {
 int dsx_free(dsx_ctx* ctx, void* d_ptr) {
   if (!ctx) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   DSX_HIP(hipFree(d_ptr));
   return DSX_OK;
 }
 int dsx_memcpy_h2d(dsx_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
   if (!ctx) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, use_main(ctx)));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   return DSX_OK;
 }
 int dsx_memcpy_d2h(dsx_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
   if (!ctx) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, use_main(ctx)));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   return DSX_OK;
 }
 int dsx_memcpy_d2d(dsx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
   if (!ctx) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  DSX_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, use_main(ctx)));
   return DSX_OK;
 }
 /* pinned host memory + copies on their own streams: the overlapped chunk map (zarr_destriper.py) */
@@ -801,7 +842,7 @@ namespace {
 hipStream_t pick_stream(dsx_ctx* ctx, int id) {
   if (id == DSX_STREAM_UPLOAD) return ctx->copy_stream[0];
   if (id == DSX_STREAM_DOWNLOAD) return ctx->copy_stream[1];
-  return ctx->stream;
+  return use_main(ctx);
 }
 bool stream_id_ok(int id) { return id == DSX_STREAM_COMPUTE || id == DSX_STREAM_UPLOAD || id == DSX_STREAM_DOWNLOAD; }
 }  // namespace
@@ -859,13 +900,13 @@ int dsx_stream_sync(dsx_ctx* ctx, int stream_id) {
 int dsx_timer_start(dsx_ctx* ctx) {
   if (!ctx) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipEventRecord(ctx->t0, ctx->stream));
+  DSX_HIP(hipEventRecord(ctx->t0, use_main(ctx)));
   return DSX_OK;
 }
 int dsx_timer_stop(dsx_ctx* ctx, float* ms) {
   if (!ctx || !ms) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipEventRecord(ctx->t1, ctx->stream));
+  DSX_HIP(hipEventRecord(ctx->t1, use_main(ctx)));
   DSX_HIP(hipEventSynchronize(ctx->t1));
   DSX_HIP(hipEventElapsedTime(ms, ctx->t0, ctx->t1));
   return DSX_OK;
@@ -873,7 +914,7 @@ int dsx_timer_stop(dsx_ctx* ctx, float* ms) {
 int dsx_profile_enable(dsx_ctx* ctx, int on) {
   if (!ctx) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   ctx->prof.clear();
   ctx->profiling = on != 0;
@@ -883,7 +924,7 @@ int dsx_profile_read(dsx_ctx* ctx, int max_classes, float* ms, int32_t* launches
                      int* n_classes) {
   if (!ctx || !ms || !launches || !n_classes) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   const int nc = std::min<int>(max_classes, KC_COUNT);
   for (int i = 0; i < nc; ++i) { ms[i] = 0.f; launches[i] = 0; if (names) names[i] = kClassNames[i]; }
   for (auto& r : ctx->prof) {
@@ -922,10 +963,10 @@ int dsx_bricks_to_planes_u16(dsx_ctx* ctx, const void* d_bricks, void* d_planes,
   const int v = retile_vec(d_bricks, d_planes, W, cx);
   const dim3 grid((W / v + 255) / 256, H, Z);
   switch (v) {
-    case 8: hipLaunchKernelGGL(dsx::k_bricks_to_planes<8>, grid, dim3(256), 0, ctx->stream, a); break;
-    case 4: hipLaunchKernelGGL(dsx::k_bricks_to_planes<4>, grid, dim3(256), 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL(dsx::k_bricks_to_planes<2>, grid, dim3(256), 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL(dsx::k_bricks_to_planes<1>, grid, dim3(256), 0, ctx->stream, a); break;
+    case 8: hipLaunchKernelGGL(dsx::k_bricks_to_planes<8>, grid, dim3(256), 0, use_main(ctx), a); break;
+    case 4: hipLaunchKernelGGL(dsx::k_bricks_to_planes<4>, grid, dim3(256), 0, use_main(ctx), a); break;
+    case 2: hipLaunchKernelGGL(dsx::k_bricks_to_planes<2>, grid, dim3(256), 0, use_main(ctx), a); break;
+    default: hipLaunchKernelGGL(dsx::k_bricks_to_planes<1>, grid, dim3(256), 0, use_main(ctx), a); break;
   }
   DSX_HIP(hipGetLastError());
   return DSX_OK;
@@ -941,10 +982,10 @@ int dsx_planes_to_bricks_u16(dsx_ctx* ctx, const void* d_planes, void* d_bricks,
   const int v = retile_vec(d_bricks, d_planes, W, cx);
   const dim3 grid((a.nbx * cx / v + 255) / 256, a.nby * cy, a.nbz * cz);
   switch (v) {
-    case 8: hipLaunchKernelGGL(dsx::k_planes_to_bricks<8>, grid, dim3(256), 0, ctx->stream, a); break;
-    case 4: hipLaunchKernelGGL(dsx::k_planes_to_bricks<4>, grid, dim3(256), 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL(dsx::k_planes_to_bricks<2>, grid, dim3(256), 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL(dsx::k_planes_to_bricks<1>, grid, dim3(256), 0, ctx->stream, a); break;
+    case 8: hipLaunchKernelGGL(dsx::k_planes_to_bricks<8>, grid, dim3(256), 0, use_main(ctx), a); break;
+    case 4: hipLaunchKernelGGL(dsx::k_planes_to_bricks<4>, grid, dim3(256), 0, use_main(ctx), a); break;
+    case 2: hipLaunchKernelGGL(dsx::k_planes_to_bricks<2>, grid, dim3(256), 0, use_main(ctx), a); break;
+    default: hipLaunchKernelGGL(dsx::k_planes_to_bricks<1>, grid, dim3(256), 0, use_main(ctx), a); break;
   }
   DSX_HIP(hipGetLastError());
   return DSX_OK;
@@ -960,8 +1001,8 @@ int dsx_downsample2_u16(dsx_ctx* ctx, const void* d_src, void* d_dst, int Z, int
   DSX_HIP(hipSetDevice(ctx->device));
   const dim3 grid(((a.Xo + 3) / 4 + 255) / 256, a.Yo, a.Zo);
   const bool vec = X % 8 == 0 && (uintptr_t)d_src % 16 == 0 && (uintptr_t)d_dst % 8 == 0;
-  if (vec) hipLaunchKernelGGL(dsx::k_downsample2<true>, grid, dim3(256), 0, ctx->stream, a);
-  else hipLaunchKernelGGL(dsx::k_downsample2<false>, grid, dim3(256), 0, ctx->stream, a);
+  if (vec) hipLaunchKernelGGL(dsx::k_downsample2<true>, grid, dim3(256), 0, use_main(ctx), a);
+  else hipLaunchKernelGGL(dsx::k_downsample2<false>, grid, dim3(256), 0, use_main(ctx), a);
   DSX_HIP(hipGetLastError());
   return DSX_OK;
 }
@@ -978,8 +1019,8 @@ int dsx_flatfield_correction(dsx_ctx* ctx, const void* d_img, int in_dtype, int 
   a.H = H; a.W = W; a.dark_w = dark_w; a.baseline = baseline;
   DSX_HIP(hipSetDevice(ctx->device));
   const dim3 grid((W + 255) / 256, H);
-  if (in_dtype == DSX_U16) hipLaunchKernelGGL(dsx::k_shade<true>, grid, dim3(256), 0, ctx->stream, a);
-  else hipLaunchKernelGGL(dsx::k_shade<false>, grid, dim3(256), 0, ctx->stream, a);
+  if (in_dtype == DSX_U16) hipLaunchKernelGGL(dsx::k_shade<true>, grid, dim3(256), 0, use_main(ctx), a);
+  else hipLaunchKernelGGL(dsx::k_shade<false>, grid, dim3(256), 0, use_main(ctx), a);
   DSX_HIP(hipGetLastError());
   return DSX_OK;
 }
@@ -994,17 +1035,17 @@ int dsx_foreground_background(dsx_ctx* ctx, const void* d_img, int in_dtype, siz
   DSX_HIP(hipMalloc(&d_acc, 32));
   int rc = DSX_OK;
   do {
-    if (hipMemsetAsync(d_acc, 0, 32, ctx->stream) != hipSuccess) { rc = DSX_EHIP; break; }
+    if (hipMemsetAsync(d_acc, 0, 32, use_main(ctx)) != hipSuccess) { rc = DSX_EHIP; break; }
     dsx::FgBgArgs a;
     a.src = d_img; a.mask = (uint8_t*)d_mask; a.acc = (double*)d_acc; a.cnt = (unsigned long long*)(d_acc + 16);
     a.n = n; a.cutoff = cutoff;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
-    if (in_dtype == DSX_U16) hipLaunchKernelGGL(dsx::k_fgbg<true>, dim3(blocks), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(dsx::k_fgbg<false>, dim3(blocks), dim3(256), 0, ctx->stream, a);
+    if (in_dtype == DSX_U16) hipLaunchKernelGGL(dsx::k_fgbg<true>, dim3(blocks), dim3(256), 0, use_main(ctx), a);
+    else hipLaunchKernelGGL(dsx::k_fgbg<false>, dim3(blocks), dim3(256), 0, use_main(ctx), a);
     char h[32];
     if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(h, d_acc, 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = DSX_EHIP; break; }
+        hipMemcpyAsync(h, d_acc, 32, hipMemcpyDeviceToHost, use_main(ctx)) != hipSuccess ||
+        hipStreamSynchronize(use_main(ctx)) != hipSuccess) { rc = DSX_EHIP; break; }
     const double* acc = (const double*)h;
     const unsigned long long* cnt = (const unsigned long long*)(h + 16);
     // an empty class has mean 0.0 (filtering.py:84-85)
@@ -1093,7 +1134,7 @@ int dsx_comm_destroy(dsx_ctx* ctx) {
   if (!ctx) return DSX_EINVAL;
   if (ctx->comm) {
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(use_main(ctx));
     (void)g_rccl.comm_destroy(ctx->comm);
     ctx->comm = nullptr;
   }
@@ -1108,8 +1149,8 @@ int dsx_comm_broadcast(dsx_ctx* ctx, void* d_buf, size_t bytes, int root) {
   if (!ctx->comm) return fail(ctx, DSX_ECOMM, "dsx_comm_init has not been called");
   if (root < 0 || root >= ctx->comm_world) return fail(ctx, DSX_EINVAL, "root out of range");
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_NCCL(g_rccl.broadcast(d_buf, d_buf, bytes, ncclUint8, root, ctx->comm, ctx->stream));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_NCCL(g_rccl.broadcast(d_buf, d_buf, bytes, ncclUint8, root, ctx->comm, use_main(ctx)));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   return DSX_OK;
 }
 
@@ -1119,10 +1160,10 @@ int dsx_comm_allreduce_f64(dsx_ctx* ctx, double* values, int n, int op) {
   const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
   if (op < 0 || op > 2) return fail(ctx, DSX_EINVAL, "reduction: 0 sum, 1 max, 2 min");
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipMemcpyAsync(ctx->d_red, values, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-  DSX_NCCL(g_rccl.all_reduce(ctx->d_red, ctx->d_red, n, ncclDouble, ops[op], ctx->comm, ctx->stream));
-  DSX_HIP(hipMemcpyAsync(values, ctx->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipMemcpyAsync(ctx->d_red, values, sizeof(double) * n, hipMemcpyHostToDevice, use_main(ctx)));
+  DSX_NCCL(g_rccl.all_reduce(ctx->d_red, ctx->d_red, n, ncclDouble, ops[op], ctx->comm, use_main(ctx)));
+  DSX_HIP(hipMemcpyAsync(values, ctx->d_red, sizeof(double) * n, hipMemcpyDeviceToHost, use_main(ctx)));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   return DSX_OK;
 }
 
@@ -1153,7 +1194,7 @@ int dsx_get_stats(dsx_ctx* ctx, int plane, double* fore_mean, double* back_mean,
   if (!ctx->planned) return fail(ctx, DSX_ENOPLAN, "dsx_plan has not been called");
   if (plane < 0 || plane >= ctx->last_n) return fail(ctx, DSX_EINVAL, "plane index outside the last cohort");
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   double m[2];
   int c = 0;
   DSX_HIP(hipMemcpy(m, ctx->d_means + 2 * plane, sizeof(m), hipMemcpyDeviceToHost));
@@ -1169,7 +1210,7 @@ int dsx_get_thresholds(dsx_ctx* ctx, int plane, int level, float* otsu, float* t
   if (plane < 0 || plane >= ctx->last_n || level < 0 || level >= ctx->plan.L)
     return fail(ctx, DSX_EINVAL, "plane / level index out of range");
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   const size_t i = (size_t)plane * ctx->plan.L + level;
   if (otsu) DSX_HIP(hipMemcpy(otsu, ctx->d_otsu + i, sizeof(float), hipMemcpyDeviceToHost));
   if (threshold) DSX_HIP(hipMemcpy(threshold, ctx->d_thr + i, sizeof(float), hipMemcpyDeviceToHost));
@@ -1181,7 +1222,7 @@ int dsx_get_level(dsx_ctx* ctx, int plane, int level, int stage, float* out) {
   if (plane < 0 || plane >= ctx->last_n || level < 0 || level >= ctx->plan.L)
     return fail(ctx, DSX_EINVAL, "plane / level index out of range");
   DSX_HIP(hipSetDevice(ctx->device));
-  DSX_HIP(hipStreamSynchronize(ctx->stream));
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
   const dsx::LevelPlan& lp = ctx->plan.lv[level];
   const long long off = (stage == DSX_STAGE_APPROX) ? lp.aa_off : lp.da_off;
   const int pitch = (stage == DSX_STAGE_APPROX) ? lp.lda : lp.ld;
