@@ -310,6 +310,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     f.lvl = l; f.L = L;
     f.stats = v.stats;
     f.fg_cutoff = ctx->fg_cutoff;
+    f.fg_cutoff_u16 = (unsigned)std::min(65536.0, std::max(0.0, ceil((double)ctx->fg_cutoff)));
     f.nstrips = (lp.w + dsx::kMarchOut - 1) / dsx::kMarchOut;
     march_segments(nb, f.nstrips, lp.h, &f.nseg, &f.rows_per_seg);
     if (fuse12 && l == 0) {

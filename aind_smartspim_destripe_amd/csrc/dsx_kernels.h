@@ -134,6 +134,7 @@ struct Fwd1Args {
   int lvl, L;
   PlaneStats* stats;
   float fg_cutoff;
+  unsigned fg_cutoff_u16;  // integer pixels: pixel >= fg_cutoff_u16  <=>  (float)pixel >= fg_cutoff
   int nstrips, nseg, rows_per_seg;
   // FUSE (k_fwd_march<IN_KIND, true>): the level-2 analysis runs in the same wave, aa_1 never leaves the
   // chip.  Strips are then counted in level-2 columns (kFuseOut per wave), segments in level-2 rows.
@@ -286,23 +287,30 @@ __device__ __forceinline__ void march_consume(const Fwd1Args& a, const MarchRaw&
                                               float (&x)[4]) {
   if (IN_KIND == 0) {
     unsigned u0 = __float_as_uint(r.f.x), u1 = __float_as_uint(r.f.y);
-    if (any_rev && c.rev) {  // mirrored group: reverse the four 16-bit elements (edge strips only)
-      const unsigned t = u0;
-      u0 = (u1 >> 16) | (u1 << 16);
-      u1 = (t >> 16) | (t << 16);
+    if (any_rev) {  // wave-uniform (scalar branch): only edge strips hold mirrored groups
+      if (c.rev) {  // mirrored group: reverse the four 16-bit elements
+        const unsigned t = u0;
+        u0 = (u1 >> 16) | (u1 << 16);
+        u1 = (t >> 16) | (t << 16);
+      }
     }
     if (row_in_seg && gr_raw >= 0 && gr_raw < a.H) {  // wave-uniform: this row is accounted by this segment
       // ownership per element as AND masks (zeroed pixels add nothing and are below the cut-off)
       const unsigned o0 = u0 & c.own_mask[0], o1 = u1 & c.own_mask[1];
-      // sum of the four pixels by two SADs against zero; foreground pixels (>= 384) are rare: a
-      // packed max decides whether the per-pixel path is needed at all
+      // sum of the four pixels by two SADs against zero; foreground pixels (>= 384) are rare: a packed
+      // 16-bit max decides whether the per-pixel path is needed at all (integer pixels: f >= cut-off
+      // <=> pixel >= ceil(cut-off))
       st.isum_all = __builtin_amdgcn_sad_u16(o1, 0u, __builtin_amdgcn_sad_u16(o0, 0u, st.isum_all));
-      const unsigned m = max(max(o0 & 0xFFFFu, o0 >> 16), max(o1 & 0xFFFFu, o1 >> 16));
-      if ((float)m >= a.fg_cutoff) {
+      typedef unsigned short dsx_u16x2 __attribute__((ext_vector_type(2)));
+      union { unsigned u; dsx_u16x2 v; } pa, pb, pm;
+      pa.u = o0; pb.u = o1;
+      pm.v = __builtin_elementwise_max(pa.v, pb.v);
+      const unsigned m = max(pm.u & 0xFFFFu, pm.u >> 16);
+      if (m >= a.fg_cutoff_u16) {
         const unsigned px[4] = {o0 & 0xFFFFu, o0 >> 16, o1 & 0xFFFFu, o1 >> 16};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if ((float)px[e] >= a.fg_cutoff) { st.isum_fg += px[e]; st.cnt++; }
+          if (px[e] >= a.fg_cutoff_u16) { st.isum_fg += px[e]; st.cnt++; }
       }
     }
     x[0] = __builtin_amdgcn_logf(1.0f + (float)(u0 & 0xFFFFu));
