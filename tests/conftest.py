@@ -19,12 +19,11 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _native_library():
-    """Build libdsx_hip.so in-tree if it is not there (hipcc cross-compiles without a GPU)."""
-    lib = os.path.join(REPO, "aind_smartspim_destripe_amd", "_lib", "libdsx_hip.so")
-    if not os.path.exists(lib):
-        import __graft_entry__ as g
+    """Build libdsx_hip.so in-tree if it is missing or older than any of its sources (hipcc cross-compiles
+    without a GPU; on the GPU box the library travels with the snapshot and is up to date)."""
+    import __graft_entry__ as g
 
-        g.build()
+    g.build()
     yield
 
 
