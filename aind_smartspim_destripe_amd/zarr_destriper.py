@@ -368,6 +368,36 @@ class _DeviceBlocks:
         return sum(z1 - z0 for z0, z1 in blocks)
 
 
+_BLOCKS = {}  # one set of staging buffers per process: page-locking 2 GB of host memory costs ~0.4 s per call
+
+
+def _device_blocks(eng, src, dst, zyx, block_z, io_threads):
+    """Staging buffers for this geometry, reused from the previous tile when nothing but the stores changed
+    (a channel is tens of tiles of one shape, ``zarr_destriper.py:1231``)."""
+    key = (id(eng), tuple(zyx[1:]), tuple(src.chunks[-3:]), tuple(dst.chunks[-3:]), int(block_z))
+    cached = _BLOCKS.get("blocks")
+    if cached is not None and cached[0] == key and cached[1].eng._ctx is not None:
+        blocks = cached[1]
+        blocks.src, blocks.dst, blocks.zyx, blocks.io_threads = src, dst, zyx, int(io_threads)
+        blocks.timing = {"read_s": 0.0, "write_s": 0.0}
+        return blocks
+    if cached is not None:
+        try:
+            cached[1].close()
+        except Exception:  # the engine of the cached buffers may be gone already
+            pass
+    blocks = _DeviceBlocks(eng, src, dst, zyx, block_z, io_threads)
+    _BLOCKS["blocks"] = (key, blocks)
+    return blocks
+
+
+def release_staging():
+    """Free the cached staging buffers (pinned host + device memory) of this process."""
+    cached = _BLOCKS.pop("blocks", None)
+    if cached is not None:
+        cached[1].close()
+
+
 def _device_retile_ok(src, dst, zyx, block_z, z0, z1):
     """The device brick path needs uint16 bricks, even planes and output-chunk-aligned z blocks."""
     co = dst.chunks[-3:]
@@ -456,12 +486,9 @@ def destripe_zarr(
         flatfield, darkfield = fl._resolve_shading(shadow_correction, name.replace(".zarr", ""))
         eng = fl.get_engine(zyx[1:], cells_config, no_cells_config, 2500, flatfield, darkfield,
                             max_batch=min(block_z, 64), device=dev)  # fmt: skip
-        blocks = _DeviceBlocks(eng, src, dst, zyx, block_z, io_threads)
-        try:
-            n_planes = blocks.run_range(z0, z1)
-            eng.sync()
-        finally:
-            blocks.close()
+        blocks = _device_blocks(eng, src, dst, zyx, block_z, io_threads)
+        n_planes = blocks.run_range(z0, z1)
+        eng.sync()
         dt = time.perf_counter() - t0
         logger.info("rank %d: %d planes z[%d:%d) in %.2f s (device re-tiling, overlapped; read %.2f s, write %.2f s)",
                     rank, n_planes, z0, z1, dt, blocks.timing["read_s"], blocks.timing["write_s"])  # fmt: skip
