@@ -11,6 +11,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <string>
@@ -257,6 +258,11 @@ inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p) {
         const double c = fft_cost(m);
         if (c < best_cost) { best_cost = c; best_m = m; best_k = K; }
       }
+    }
+    // measurement hook (tools/plan_direct_vs_embedded.sh): DSX_PLAN_DIRECT_LEVEL=<l> forces the direct
+    // length-n transform at level index l whatever the cost model says
+    if (const char* fd = getenv("DSX_PLAN_DIRECT_LEVEL")) {
+      if (atoi(fd) == l && n <= kMaxFftLen) { best_m = n; best_k = 0; }
     }
     if (best_k > 0) {
       for (int c = 0; c < 2; ++c) {
