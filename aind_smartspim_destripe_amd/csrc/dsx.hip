@@ -310,6 +310,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     f.lvl = l; f.L = L;
     f.stats = v.stats;
     f.fg_cutoff = ctx->fg_cutoff;
+    f.ablate = ctx->ablate;
     f.fg_cutoff_u16 = (unsigned)std::min(65536.0, std::max(0.0, ceil((double)ctx->fg_cutoff)));
     f.nstrips = (lp.w + dsx::kMarchOut - 1) / dsx::kMarchOut;
     march_segments(nb, f.nstrips, lp.h, &f.nseg, &f.rows_per_seg);
@@ -446,6 +447,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
       f.dark = ctx->d_dark;
       f.dark_ld = ctx->dark_w;
     }
+    f.ablate = ctx->ablate;
     f.nstrips = (f.wout + dsx::kMarchCols - 1) / dsx::kMarchCols;
     march_segments(nb, f.nstrips, (f.hout + 1) / 2, &f.nseg, &f.rows_per_seg);
     const bool fused = fuse21 && last;
