@@ -323,7 +323,15 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     }
     dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
     LaunchScope ls(ctx, l == 0 ? KC_FWD1 : KC_FWD);
-    if (fuse12 && l == 0) {
+    // 8 waves per block for the fused kernels: a block covers 8 consecutive strips of one row segment (4 KB of
+    // contiguous pixels per row at 2048 columns), and at most 8 march waves sit on a CU next to the other
+    // streams' row-filter blocks: +4 % in the 4-stream run (DSX_FWD_WPB / DSX_INV_WPB = 4 restores 4)
+    static const int fwd_wpb = getenv("DSX_FWD_WPB") ? atoi(getenv("DSX_FWD_WPB")) : 8;
+    if (fuse12 && l == 0 && fwd_wpb == 8) {
+      const dim3 g8((f.nstrips * f.nseg + 7) / 8, nb);
+      if (in_dtype == DSX_U16) hipLaunchKernelGGL((dsx::k_fwd_march<0, true, 8>), g8, dim3(512), 0, s, f);
+      else hipLaunchKernelGGL((dsx::k_fwd_march<1, true, 8>), g8, dim3(512), 0, s, f);
+    } else if (fuse12 && l == 0) {
       if (in_dtype == DSX_U16) hipLaunchKernelGGL((dsx::k_fwd_march<0, true>), grid, dim3(256), 0, s, f);
       else hipLaunchKernelGGL((dsx::k_fwd_march<1, true>), grid, dim3(256), 0, s, f);
     } else if (l > 0) {
@@ -457,6 +465,9 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
       f.hc2 = l2.h; f.wc2 = l2.w; f.ldc2 = l2.lda; f.ldd2 = l2.ld;
       f.has_c2 = (L > 2) ? 1 : 0;
       f.has_c = 1;
+      static const bool no_pair = getenv("DSX_NO_PAIR") && atoi(getenv("DSX_NO_PAIR")) != 0;
+      f.pair_io = (!no_pair && in_dtype == DSX_U16 && (p.W % 8) == 0 && (p.H % 2) == 0 && p.Wout == p.W &&
+                   (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && ((size_t)p.H * p.W * 2) % 16 == 0) ? 1 : 0;
       if (f.rows_per_seg & 1) {  // segments start at even level-1 rows
         f.rows_per_seg += 1;
         f.nseg = ((f.hout + 1) / 2 + f.rows_per_seg - 1) / f.rows_per_seg;
@@ -464,7 +475,12 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     }
     dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
     LaunchScope ls(ctx, last ? KC_FINAL : KC_INV);
-    if (fused) {
+    static const int inv_wpb = getenv("DSX_INV_WPB") ? atoi(getenv("DSX_INV_WPB")) : 8;
+    if (fused && inv_wpb == 8) {
+      const dim3 g8((f.nstrips * f.nseg + 7) / 8, nb);
+      if (in_dtype == DSX_U16) hipLaunchKernelGGL((dsx::k_inv_march<0, true, 8>), g8, dim3(512), 0, s, f);
+      else hipLaunchKernelGGL((dsx::k_inv_march<1, true, 8>), g8, dim3(512), 0, s, f);
+    } else if (fused) {
       if (in_dtype == DSX_U16) hipLaunchKernelGGL((dsx::k_inv_march<0, true>), grid, dim3(256), 0, s, f);
       else hipLaunchKernelGGL((dsx::k_inv_march<1, true>), grid, dim3(256), 0, s, f);
     } else if (!last) {

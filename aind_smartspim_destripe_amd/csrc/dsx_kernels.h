@@ -682,14 +682,15 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
 #ifndef DSX_INV_BOUNDS
 #define DSX_INV_BOUNDS 256
 #endif
-template <int IN_KIND, bool FUSE = false>
-__global__ __launch_bounds__(DSX_FWD_BOUNDS) void k_fwd_march(Fwd1Args a) {
-  __shared__ __attribute__((aligned(16))) float s_row[4][2][2][kMarchCols / 2];  // [wave][lo|hi][parity][col/2]
-  __shared__ __attribute__((aligned(16))) float s_ring[FUSE ? 4 : 1][kRingRows][FUSE ? kRingPitch : 4];
-  __shared__ __attribute__((aligned(16))) float2 s_x2[FUSE ? 4 : 1][FUSE ? kX2Pitch : 2];
+// WPB: waves per block (consecutive strips of one row segment: a block reads WPB x 512 contiguous bytes per row)
+template <int IN_KIND, bool FUSE = false, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_fwd_march(Fwd1Args a) {
+  __shared__ __attribute__((aligned(16))) float s_row[WPB][2][2][kMarchCols / 2];  // [wave][lo|hi][parity][col/2]
+  __shared__ __attribute__((aligned(16))) float s_ring[FUSE ? WPB : 1][kRingRows][FUSE ? kRingPitch : 4];
+  __shared__ __attribute__((aligned(16))) float2 s_x2[FUSE ? WPB : 1][FUSE ? kX2Pitch : 2];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps row math on the SALU
-  const int item = blockIdx.x * 4 + wave;
+  const int item = blockIdx.x * WPB + wave;
   if (item >= a.nstrips * a.nseg) return;
   const int strip = item % a.nstrips, seg = item / a.nstrips;
   const int plane = blockIdx.y;
@@ -1516,6 +1517,7 @@ struct FinalArgs {
   long long c2_off, d2_off;
   int hc2, wc2, ldc2, ldd2, has_c2;
   int ablate;  // diagnosis only (DSX_ABLATE): 32 = the final kernel stores nothing
+  int pair_io;  // FUSE, uint16 planes: 16-byte pixel loads / result stores by lane pairs (see inv_march_body)
 };
 constexpr int kC1Pitch = 136;  // floats per c_1 ring row: 33 lanes x 4 columns (130 are needed)
 
@@ -1526,6 +1528,7 @@ template <int IN_KIND>
 struct FinalRawI {  // raw pixels x0 .. x0+3 of one plane row
   uint2 u;
   float4 f;
+  uint4 q;  // PAIR: 8 pixels of row 2p + (lane & 1) starting at the lane pair's first column
 };
 
 __device__ __forceinline__ void final_coeff_row(const FinalArgs& a, const float* base, int pitch, int p, int q,
@@ -1565,6 +1568,11 @@ __device__ __forceinline__ dsx_f2 pk_dot6(dsx_f2 a0, float t0, dsx_f2 a1, float 
   return v;
 }
 
+// value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ unsigned swap_adjacent(unsigned v) {
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+
 // c0l = c0 * log2(e) (the factor is folded into the axis-0 synthesis taps of the last level)
 template <bool SHADE>
 __device__ __forceinline__ float final_px(const FinalArgs& a, float c0l, float x, float dark, float flat) {
@@ -1580,7 +1588,11 @@ __device__ __forceinline__ float final_px(const FinalArgs& a, float c0l, float x
 // Body of k_inv_march for one wave.  FAST: every lane loads its coefficients / pixels with aligned
 // vector loads, unconditionally (row indices are clamped: rows past the end only feed result rows
 // that are never stored) -- see fwd_march_body for why this is a separate instantiation.
-template <int IN_KIND, bool FAST, bool SHADE, bool FUSE = false>
+// PAIR (uint16 pixels, width a multiple of 8): pixel rows are read and result rows written by lane PAIRS -- the even
+// lane moves 16 bytes of row 2p, the odd lane 16 bytes of row 2p + 1, and the halves are exchanged with one DPP
+// swap each way.  A streaming kernel with 8-byte accesses per lane tops out at 3.9 TB/s on this chip, with 16-byte
+// accesses at 6.3 TB/s (tools/bw_access_width.py), and this kernel's time is proportional to its bytes.
+template <int IN_KIND, bool FAST, bool SHADE, bool FUSE = false, bool PAIR = false>
 __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int strip, int seg, int plane,
                                                float (*s_c1)[kC1Pitch] = nullptr) {
   constexpr float RL0[6] = DSX_REC_LO;
@@ -1702,10 +1714,22 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     final_coeff_row(a, dbase, a.ldd, p, q, pyr, vec_c, r.d01, r.d23);
     return r;
   };
+  const bool odd_lane = (lane & 1) != 0;
+  const int xb = min(kMarchCols * strip + 8 * (lane >> 1), a.W - 8);  // PAIR: first column of the lane pair (clamped)
   auto issue_i = [&](int gy) {
     FinalRawI<IN_KIND> r;
     r.u = make_uint2(0u, 0u);
     r.f = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.q = make_uint4(0u, 0u, 0u, 0u);
+    if (PAIR) {
+      if ((gy & 1) == 0) {  // one load per row pair, issued with the even row
+        typedef unsigned dsx_u32x4 __attribute__((ext_vector_type(4)));
+        const long long off = img_plane + (long long)min(gy + (odd_lane ? 1 : 0), a.H - 1) * a.W + xb;
+        const dsx_u32x4 u = __builtin_nontemporal_load((const dsx_u32x4*)((const uint16_t*)a.img + off));
+        r.q = make_uint4(u.x, u.y, u.z, u.w);
+      }
+      return r;
+    }
     if (IN_KIND != 2 && (FAST || vec_in)) {
       const long long off = img_plane + (long long)min(gy, a.H - 1) * a.W + xl;
       if (IN_KIND == 0) {
@@ -1730,9 +1754,9 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     final_xsynth(r1.d01, r1.d23, D[1]);
   }
 
-  auto emit_row = [&](int gy, const FinalRawI<IN_KIND>& raw, const dsx_f2 (&c0p)[2]) {
+  auto emit_row = [&](int gy, const FinalRawI<IN_KIND>& raw, const dsx_f2 (&c0p)[2], unsigned (*pk_out)[2] = nullptr) {
     const float c0[4] = {c0p[0].x, c0p[0].y, c0p[1].x, c0p[1].y};
-    if (gy >= a.hout) return;
+    if (gy >= a.hout && pk_out == nullptr) return;
     if (IN_KIND == 2) {
       float* dst = a.ws_out + plane * a.ws_plane_stride + a.out_off + (long long)gy * a.ldout + x0;
       if (vec_out) {
@@ -1780,6 +1804,14 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     float r[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] = final_px<SHADE>(a, c0[e], px[e], dk[e], fl[e]);  // all four: stores are masked
+    if (pk_out != nullptr) {  // PAIR: hand the packed uint16 row back, the caller stores row pairs
+      unsigned u[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u[e] = (unsigned)fminf(r[e], 65535.f);
+      (*pk_out)[0] = u[0] | (u[1] << 16);
+      (*pk_out)[1] = u[2] | (u[3] << 16);
+      return;
+    }
     const long long o = plane * a.out_plane_stride + (long long)gy * a.wout + x0;
     if (a.ablate & 32) {
       if (r[0] + r[1] + r[2] + r[3] == -12345.f) ((float*)a.out)[0] = 0.f;  // keeps the arithmetic alive
@@ -1823,8 +1855,39 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
       even[h] = pk_dot6(A0[h], RL[4], A1[h], RL[2], A2[h], RL[0], D0[h], RH[4], D1[h], RH[2], D2[h], RH[0]);
       odd[h] = pk_dot6(A0[h], RL[5], A1[h], RL[3], A2[h], RL[1], D0[h], RH[5], D1[h], RH[3], D2[h], RH[1]);
     }
-    emit_row(2 * p, ri0, even);
-    emit_row(2 * p + 1, ri1, odd);
+    if (PAIR) {
+      // ri0.q: this lane's 16 bytes of row 2p + (lane & 1); the own half of the own row stays, the other
+      // row's own half comes from the neighbour
+      const unsigned sx = odd_lane ? ri0.q.x : ri0.q.z, sy = odd_lane ? ri0.q.y : ri0.q.w;  // what the neighbour needs
+      const unsigned gx = swap_adjacent(sx), gyv = swap_adjacent(sy);
+      FinalRawI<IN_KIND> r0 = ri0, r1 = ri0;
+      r0.u = odd_lane ? make_uint2(gx, gyv) : make_uint2(ri0.q.x, ri0.q.y);      // row 2p, own 4 columns
+      r1.u = odd_lane ? make_uint2(ri0.q.z, ri0.q.w) : make_uint2(gx, gyv);      // row 2p + 1
+      if (a.out_dtype == 0 && !(a.ablate & 32)) {
+        unsigned pe[2], po[2];
+        emit_row(2 * p, r0, even, &pe);
+        emit_row(2 * p + 1, r1, odd, &po);
+        // even lane stores row 2p: [own | neighbour's] even-row pack; odd lane row 2p + 1: [neighbour's | own]
+        const unsigned tx = swap_adjacent(odd_lane ? pe[0] : po[0]), ty = swap_adjacent(odd_lane ? pe[1] : po[1]);
+        typedef unsigned dsx_u32x4 __attribute__((ext_vector_type(4)));
+        dsx_u32x4 o4;
+        o4.x = odd_lane ? tx : pe[0];
+        o4.y = odd_lane ? ty : pe[1];
+        o4.z = odd_lane ? po[0] : tx;
+        o4.w = odd_lane ? po[1] : ty;
+        const int gyl = 2 * p + (odd_lane ? 1 : 0);
+        if (gyl < a.hout && x0 < a.wout) {
+          const long long o = plane * a.out_plane_stride + (long long)gyl * a.wout + xb;
+          __builtin_nontemporal_store(o4, (dsx_u32x4*)((uint16_t*)a.out + o));
+        }
+      } else {
+        emit_row(2 * p, r0, even);
+        emit_row(2 * p + 1, r1, odd);
+      }
+    } else {
+      emit_row(2 * p, ri0, even);
+      emit_row(2 * p + 1, ri1, odd);
+    }
   };
 
   // software prefetch: coefficient rows p+2..p+4 and plane rows 2p..2p+5 of the NEXT group of three
@@ -1857,12 +1920,12 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
 
 // IN_KIND: 0 = last level, uint16 pixels; 1 = last level, float32 pixels;
 //          2 = pyramid level: writes c_{l-1} (float32, hout x wout, pitch ldout) into the workspace
-template <int IN_KIND, bool FUSE = false>
-__global__ __launch_bounds__(DSX_INV_BOUNDS) void k_inv_march(FinalArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_c1[FUSE ? 4 : 1][FUSE ? kRingRows : 1][FUSE ? kC1Pitch : 4];
+template <int IN_KIND, bool FUSE = false, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_inv_march(FinalArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_c1[FUSE ? WPB : 1][FUSE ? kRingRows : 1][FUSE ? kC1Pitch : 4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps row math on the SALU
-  const int item = blockIdx.x * 4 + wave;
+  const int item = blockIdx.x * WPB + wave;
   if (item >= a.nstrips * a.nseg) return;
   const int strip = item % a.nstrips, seg = item / a.nstrips;
   const int plane = blockIdx.y;
@@ -1872,6 +1935,12 @@ __global__ __launch_bounds__(DSX_INV_BOUNDS) void k_inv_march(FinalArgs a) {
     // host guarantees W % 4 == 0 and even coefficient pitches; lanes right of the plane stay in the wave
     // (lanes 0..32 synthesise c_1 for everybody) and simply store nothing
     float (*ring)[kC1Pitch] = (float (*)[kC1Pitch])s_c1[wave];
+    const bool pair = IN_KIND == 0 && a.pair_io != 0;  // host: uint16 planes, W % 8 == 0, 16-byte aligned bases
+    if (IN_KIND == 0 && pair) {
+      if (a.flat != nullptr) inv_march_body<IN_KIND, true, true, true, IN_KIND == 0>(a, lane, strip, seg, plane, ring);
+      else inv_march_body<IN_KIND, true, false, true, IN_KIND == 0>(a, lane, strip, seg, plane, ring);
+      return;
+    }
     if (a.flat != nullptr) inv_march_body<IN_KIND, true, true, true>(a, lane, strip, seg, plane, ring);
     else inv_march_body<IN_KIND, true, false, true>(a, lane, strip, seg, plane, ring);
     return;
