@@ -87,6 +87,10 @@ struct dsx_ctx {
   // Cross-call pipelining of the sub-cohort streams: the joins of a split cohort are deferred until something
   // else needs the context stream, so that an identical run_device call that follows (the next batch of a
   // steady stream of batches) starts each part right behind the same part of the call before it.
+  // Helper stream per part: the wide levels' histogram / row filter run beside the coarse levels' launches
+  // (small grids that leave most of the chip idle), see run_cohort
+  hipStream_t helper[kMaxStreams] = {};
+  hipEvent_t ev_h[kMaxStreams][4] = {};
   int joins_pending = 0;              // parts (incl. part 0) of a split cohort the context stream has not joined yet
   unsigned long long main_ops = 0;    // operations entry points put on the context stream (use_main calls)
   struct {
@@ -110,6 +114,8 @@ namespace {
 // Buffers of one part of a cohort (planes [po, po + nb) of the workspace) and the stream it runs on.
 struct CohortView {
   hipStream_t stream;
+  hipStream_t helper;   // nullptr: everything on `stream`
+  hipEvent_t* ev;       // 4 events of this part (helper fork / join, twice)
   float* ws;
   dsx::PlaneStats* stats;
   unsigned* minmax;
@@ -293,6 +299,31 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   static const bool no_fuse = getenv("DSX_NO_FUSE") && atoi(getenv("DSX_NO_FUSE")) != 0;
   const bool fuse12 = !no_fuse && L >= 2 && (p.W % 4) == 0 && (p.lv[0].ldin % 4) == 0 && p.lv[0].h >= 16 &&
                       p.lv[0].w >= 16;
+  static const bool no_fuse_inv = getenv("DSX_NO_FUSE_INV") && atoi(getenv("DSX_NO_FUSE_INV")) != 0;
+  const bool fuse21 = fuse12 && !no_fuse_inv;
+  // The wide levels (1, 2) hold 94 % of the coefficients; the coarse levels are chains of small launches that
+  // leave most of the chip idle.  With the fused forward kernel the wide levels' data is complete early, so
+  // their histograms (and, below, their row filters) run on the part's helper stream BESIDE the coarse
+  // levels' launches instead of after them.
+  const bool split = v.helper != nullptr && fuse12 && L >= 3;
+  auto hist_level = [&](int l, hipStream_t hs) -> int {
+    const dsx::LevelPlan& lp = p.lv[l];
+    dsx::HistArgs a;
+    a.ws = v.ws;
+    a.ws_plane_stride = p.plane_floats;
+    a.da_off = lp.da_off;
+    a.h = lp.h; a.w = lp.w; a.ld = lp.ld;
+    a.minmax = v.minmax;
+    a.hist = v.hist;
+    a.lvl = l; a.L = L;
+    static const int hist_rows = getenv("DSX_HIST_ROWS") ? atoi(getenv("DSX_HIST_ROWS")) : 32;
+    a.rows_per_block = hist_rows;
+    dim3 grid((lp.h + a.rows_per_block - 1) / a.rows_per_block, nb);
+    LaunchScope ls(ctx, KC_HIST);
+    hipLaunchKernelGGL(dsx::k_hist, grid, dim3(256), 0, hs, a);
+    DSX_HIP(hipGetLastError());
+    return DSX_OK;
+  };
   for (int l = 0; l < L; ++l) {
     if (fuse12 && l == 1) continue;
     const dsx::LevelPlan& lp = p.lv[l];
@@ -342,29 +373,19 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
       hipLaunchKernelGGL(dsx::k_fwd_march<1>, grid, dim3(256), 0, s, f);
     }
     DSX_HIP(hipGetLastError());
-  }
-  if (L == 0) {
-    // no level runs: the statistic is not needed (both configs are the identity + 2)
+    if (split && l == 0) {  // levels 1 and 2 are complete: their histograms start now, on the helper stream
+      DSX_HIP(hipEventRecord(v.ev[0], s));
+      DSX_HIP(hipStreamWaitEvent(v.helper, v.ev[0], 0));
+      if (int rc = hist_level(0, v.helper)) return rc;
+      if (int rc = hist_level(1, v.helper)) return rc;
+      DSX_HIP(hipEventRecord(v.ev[1], v.helper));
+    }
   }
 
   // ---- thresholds -----------------------------------------------------------------------------
-  for (int l = 0; l < L; ++l) {
-    const dsx::LevelPlan& lp = p.lv[l];
-    dsx::HistArgs a;
-    a.ws = v.ws;
-    a.ws_plane_stride = p.plane_floats;
-    a.da_off = lp.da_off;
-    a.h = lp.h; a.w = lp.w; a.ld = lp.ld;
-    a.minmax = v.minmax;
-    a.hist = v.hist;
-    a.lvl = l; a.L = L;
-    static const int hist_rows = getenv("DSX_HIST_ROWS") ? atoi(getenv("DSX_HIST_ROWS")) : 32;
-    a.rows_per_block = hist_rows;
-    dim3 grid((lp.h + a.rows_per_block - 1) / a.rows_per_block, nb);
-    LaunchScope ls(ctx, KC_HIST);
-    hipLaunchKernelGGL(dsx::k_hist, grid, dim3(256), 0, s, a);
-    DSX_HIP(hipGetLastError());
-  }
+  for (int l = split ? 2 : 0; l < L; ++l)
+    if (int rc = hist_level(l, s)) return rc;
+  if (split) DSX_HIP(hipStreamWaitEvent(s, v.ev[1], 0));  // histograms of levels 1, 2 (helper stream)
   if (L > 0) {
     dsx::OtsuArgs a;
     a.stats = v.stats;
@@ -390,7 +411,15 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   if (ctx->stop_after == 1) return DSX_OK;
 
   // ---- row filter -----------------------------------------------------------------------------
+  // split: levels 1, 2 on the helper stream (1.5 ms of the 5.3 ms chain per 256 planes), the coarse levels'
+  // row filters AND the coarse inverse levels on the part's own stream beside them; joined before the final kernel
+  const bool split_inv = split && fuse21;  // the fused final kernel consumes Delta_1, Delta_2 and c_2 only
+  if (split_inv) {
+    DSX_HIP(hipEventRecord(v.ev[2], s));                  // thresholds are known
+    DSX_HIP(hipStreamWaitEvent(v.helper, v.ev[2], 0));
+  }
   for (int l = 0; l < L; ++l) {
+    hipStream_t rs = (split_inv && l < 2) ? v.helper : s;
     const dsx::LevelPlan& lp = p.lv[l];
     dsx::RowArgs a;
     memset(&a, 0, sizeof(a));
@@ -415,14 +444,13 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.ablate = ctx->ablate;
     const int npairs = (lp.h + 1) / 2;
     LaunchScope ls(ctx, KC_ROW);
-    DSX_HIP(dispatch_rowfilter(a, npairs, nb, s));
+    DSX_HIP(dispatch_rowfilter(a, npairs, nb, rs));
   }
+  if (split_inv) DSX_HIP(hipEventRecord(v.ev[3], v.helper));
   if (ctx->stop_after == 2) return DSX_OK;
 
   // ---- inverse transform of the Delta pyramid + finish ---------------------------------------
-  // level-2 synthesis inside the final kernel when the plane allows it (c_1 never leaves the chip)
-  static const bool no_fuse_inv = getenv("DSX_NO_FUSE_INV") && atoi(getenv("DSX_NO_FUSE_INV")) != 0;
-  const bool fuse21 = fuse12 && !no_fuse_inv;
+  // level-2 synthesis inside the final kernel when the plane allows it (c_1 never leaves the chip): fuse21
   for (int l = L - 1; l >= (L > 0 ? 0 : -1); --l) {
     if (fuse21 && l == 1) continue;
     dsx::FinalArgs f;
@@ -459,6 +487,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     f.nstrips = (f.wout + dsx::kMarchCols - 1) / dsx::kMarchCols;
     march_segments(nb, f.nstrips, (f.hout + 1) / 2, &f.nseg, &f.rows_per_seg);
     const bool fused = fuse21 && last;
+    if (last && split_inv) DSX_HIP(hipStreamWaitEvent(s, v.ev[3], 0));  // Delta_1, Delta_2 (helper stream)
     if (fused) {
       const dsx::LevelPlan& l2 = p.lv[1];
       f.c2_off = l2.aa_off; f.d2_off = l2.da_off;
@@ -497,10 +526,18 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
 
 size_t elem_size(int dtype) { return dtype == DSX_U16 ? 2 : 4; }
 
-CohortView make_view(dsx_ctx* ctx, int po, hipStream_t stream) {
+// helper: 1 = this part may use its helper stream (run_cohort).  Measured at 2048^2: a cohort that runs as ONE
+// part gains 6 % (52.5 k against 49.5 k planes/s), a cohort split over 4 streams LOSES 2-8 % (the other parts
+// already fill the chip, the extra streams only add contention), so only unsplit cohorts use it; DSX_HELPER=0 / 1
+// forces it off / on.
+CohortView make_view(dsx_ctx* ctx, int po, hipStream_t stream, int part = 0, bool helper = false) {
   const int Lc = ctx->plan.L > 0 ? ctx->plan.L : 1;
   CohortView v;
   v.stream = stream;
+  static const int force_helper = getenv("DSX_HELPER") ? atoi(getenv("DSX_HELPER")) : -1;
+  const bool use = force_helper >= 0 ? force_helper != 0 : helper;
+  v.helper = (!use || ctx->profiling || ctx->stop_after != 0) ? nullptr : ctx->helper[part];
+  v.ev = ctx->ev_h[part];
   v.ws = ctx->d_ws + (size_t)po * ctx->plan.plane_floats;
   v.stats = ctx->d_stats + po;
   v.minmax = ctx->d_minmax + (size_t)po * Lc * 2;
@@ -528,7 +565,7 @@ int run_cohort_split(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void*
   while (parts > 1 && nb / parts < 16) --parts;  // keep every part big enough to fill the chip
   if (parts <= 1) {
     hipStream_t main = use_main(ctx);  // joins whatever split cohort is still running
-    return run_cohort(ctx, make_view(ctx, 0, main), d_in, in_dtype, nb, d_out, out_dtype, d_cfg_used);
+    return run_cohort(ctx, make_view(ctx, 0, main, 0, true), d_in, in_dtype, nb, d_out, out_dtype, d_cfg_used);
   }
   static const bool no_pipe = getenv("DSX_NO_PIPELINE") && atoi(getenv("DSX_NO_PIPELINE")) != 0;
   auto& ls = ctx->last_split;
@@ -547,7 +584,7 @@ int run_cohort_split(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void*
     if (n <= 0) break;
     hipStream_t st = (i == 0) ? ctx->stream_ : ctx->aux[i];
     if (i > 0 && !same_call) DSX_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
-    const int rc = run_cohort(ctx, make_view(ctx, po, st), (const char*)d_in + po * in_plane, in_dtype, n,
+    const int rc = run_cohort(ctx, make_view(ctx, po, st, i), (const char*)d_in + po * in_plane, in_dtype, n,
                               (char*)d_out + po * out_plane, out_dtype, d_cfg_used ? d_cfg_used + po : nullptr);
     if (rc != DSX_OK) return rc;
     if (i > 0) DSX_HIP(hipEventRecord(ctx->ev_join[i], st));
@@ -594,6 +631,10 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking);
+  for (int i = 0; i < dsx_ctx::kMaxStreams && e == hipSuccess; ++i) {
+    e = hipStreamCreateWithFlags(&c->helper[i], hipStreamNonBlocking);
+    for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&c->ev_h[i][k], hipEventDisableTiming);
+  }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_xs, hipEventDisableTiming);
   for (int i = 0; i < dsx_ctx::kEventSlots && e == hipSuccess; ++i)
     e = hipEventCreateWithFlags(&c->ev_slot[i], hipEventDisableTiming);
@@ -622,6 +663,10 @@ void dsx_destroy(dsx_ctx* ctx) {
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  for (int i = 0; i < dsx_ctx::kMaxStreams; ++i) {
+    if (ctx->helper[i]) { (void)hipStreamSynchronize(ctx->helper[i]); (void)hipStreamDestroy(ctx->helper[i]); }
+    for (int k = 0; k < 4; ++k) if (ctx->ev_h[i][k]) (void)hipEventDestroy(ctx->ev_h[i][k]);
+  }
   for (int i = 0; i < 2; ++i)
     if (ctx->copy_stream[i]) { (void)hipStreamSynchronize(ctx->copy_stream[i]); (void)hipStreamDestroy(ctx->copy_stream[i]); }
   if (ctx->ev_xs) (void)hipEventDestroy(ctx->ev_xs);
