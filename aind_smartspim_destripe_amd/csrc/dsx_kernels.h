@@ -101,6 +101,14 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef DSX_DPP_X
+#define DSX_DPP_X 1
+#endif
+// Value of the same register in lane + 1 (DPP wave_shl:1); lane 63 reads 0.  All 64 lanes must be active.
+__device__ __forceinline__ float lane_above(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
 // One launch instead of three hipMemsetAsync calls (each ~27 us of fill-kernel + launch latency) to zero
 // the control block of a cohort part: plane statistics, min/max words, histograms (16-byte units).
 __global__ __launch_bounds__(256) void k_zero3(uint4* p0, int n0, uint4* p1, int n1, uint4* p2, int n2) {
@@ -427,6 +435,9 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   // ---- FUSE: one level-2 row from the aa_1 ring (rows 2 i2 - 4 .. 2 i2 + 1, half-sample symmetric) ----
   auto l2_step = [&](int i2) {
     dsx_f2 c[6];
+#if DSX_DPP_X
+    wave_sync();  // edge strips: the ring's mirrored columns were written by other lanes
+#endif
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       int r = 2 * i2 - 4 + k;
@@ -441,19 +452,27 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
       hi2 = pk_fma(HI[k], c[5 - k], hi2);
     }
     dsx_f4 pk = {lo2.x, hi2.x, lo2.y, hi2.y};  // (lo, hi) per column: the row pass filters both at once
+    // axis 1, low-pass only: out[o2 + t] = sum_k LO[k] x[2 t + 5 - k] (local columns), t = lane
+#if DSX_DPP_X
+    const dsx_f4 p0 = pk;  // columns 2t, 2t+1 are the lane's own; 2t+2.. come from lanes t+1, t+2 (DPP)
+    const dsx_f4 p1 = {lane_above(p0.x), lane_above(p0.y), lane_above(p0.z), lane_above(p0.w)};
+    const dsx_f4 p2 = {lane_above(p1.x), lane_above(p1.y), lane_above(p1.z), lane_above(p1.w)};
+#else
     *(dsx_f4*)&s_x2[wave][jj0] = pk;
     wave_sync();
-    // axis 1, low-pass only: out[o2 + t] = sum_k LO[k] x[2 t + 5 - k] (local columns), t = lane
     const dsx_f4 p0 = *(const dsx_f4*)&s_x2[wave][2 * lane];
     const dsx_f4 p1 = *(const dsx_f4*)&s_x2[wave][2 * lane + 2];
     const dsx_f4 p2 = *(const dsx_f4*)&s_x2[wave][2 * lane + 4];
+#endif
     dsx_f2 v = LO[5] * p0.xy;
     v = pk_fma(LO[4], p0.zw, v);
     v = pk_fma(LO[3], p1.xy, v);
     v = pk_fma(LO[2], p1.zw, v);
     v = pk_fma(LO[1], p2.xy, v);
     v = pk_fma(LO[0], p2.zw, v);
+#if !DSX_DPP_X
     wave_sync();
+#endif
     const float q = v.y * v.y;
     q2min = fminf(q2min, l2_valid ? q : __builtin_huge_valf());
     q2max = fmaxf(q2max, l2_valid ? q : 0.f);
@@ -486,6 +505,41 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
       lo[e] = fmaf(LOV[4], r1[e], lo[e]); hi[e] = fmaf(HIV[4], r1[e], hi[e]);
       lo[e] = fmaf(LOV[5], r0[e], lo[e]); hi[e] = fmaf(HIV[5], r0[e], hi[e]);
     }
+#if DSX_DPP_X
+    // axis 1, low-pass only.  A lane's two outputs need its own four columns and the first four of the lane
+    // above: those come over the DPP crossbar (wave_shl:1, lane L reads lane L + 1) -- no LDS round trip.
+    // out[jj] = LO0 x[2jj+5] + LO1 x[2jj+4] + ... + LO5 x[2jj], x = (lo[0..3], next lane's lo[0..3])
+    // The DPP operand rides on the multiply itself (v_mul/v_fmac_f32_dpp): the exchange costs no instruction.
+    // Per output the terms are added in the order LO0 .. LO5, as everywhere else in this file.
+    float res[2][2];
+    {
+      float v0l, v1l, v0h, v1h;
+      const float c0 = LO[0], c1 = LO[1], c2 = LO[2], c3 = LO[3];
+#define DSX_DPP_UP " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      asm("s_nop 1\n"  // VALU write -> DPP read of lo / hi: 2 wait states (the assembler does not see in here)
+          "v_mul_f32_dpp %0, %5, %12" DSX_DPP_UP   // v0 = LO0 n[1]
+          "v_mul_f32_dpp %1, %7, %12" DSX_DPP_UP   // v1 = LO0 n[3]
+          "v_mul_f32_dpp %2, %9, %12" DSX_DPP_UP
+          "v_mul_f32_dpp %3, %11, %12" DSX_DPP_UP
+          "v_fmac_f32_dpp %0, %4, %13" DSX_DPP_UP  // v0 += LO1 n[0]
+          "v_fmac_f32_dpp %1, %6, %13" DSX_DPP_UP  // v1 += LO1 n[2]
+          "v_fmac_f32_dpp %2, %8, %13" DSX_DPP_UP
+          "v_fmac_f32_dpp %3, %10, %13" DSX_DPP_UP
+          "v_fmac_f32_dpp %1, %5, %14" DSX_DPP_UP  // v1 += LO2 n[1]
+          "v_fmac_f32_dpp %3, %9, %14" DSX_DPP_UP
+          "v_fmac_f32_dpp %1, %4, %15" DSX_DPP_UP  // v1 += LO3 n[0]
+          "v_fmac_f32_dpp %3, %8, %15" DSX_DPP_UP
+          : "=&v"(v0l), "=&v"(v1l), "=&v"(v0h), "=&v"(v1h)
+          : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]),
+            "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+#undef DSX_DPP_UP
+      v0l = fmaf(LO[2], lo[3], v0l); v0l = fmaf(LO[3], lo[2], v0l); v0l = fmaf(LO[4], lo[1], v0l); v0l = fmaf(LO[5], lo[0], v0l);
+      v1l = fmaf(LO[4], lo[3], v1l); v1l = fmaf(LO[5], lo[2], v1l);
+      v0h = fmaf(LO[2], hi[3], v0h); v0h = fmaf(LO[3], hi[2], v0h); v0h = fmaf(LO[4], hi[1], v0h); v0h = fmaf(LO[5], hi[0], v0h);
+      v1h = fmaf(LO[4], hi[3], v1h); v1h = fmaf(LO[5], hi[2], v1h);
+      res[0][0] = v0l; res[0][1] = v1l; res[1][0] = v0h; res[1][1] = v1h;
+    }
+#else
     sE[0][lane] = make_float2(lo[0], lo[2]);
     sO[0][lane] = make_float2(lo[1], lo[3]);
     sE[1][lane] = make_float2(hi[0], hi[2]);
@@ -509,6 +563,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
       }
     }
     wave_sync();
+#endif
     if (FUSE) {
       if (out_lane) {
         const int j = jl;
