@@ -14,10 +14,29 @@
 #ifndef DSX_KERNELS_H
 #define DSX_KERNELS_H
 
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "dsx_fft_core.h"
+
+// ---- build-time switches (defaults = the product; tools/build_variant.sh builds A/B variants with -D...) ----------
+// Streaming (non-temporal) accesses for intermediates that the next kernel reads only after hundreds of MB of
+// other traffic (da_1 out of the forward kernel, cH into the histogram, Delta out of the row filter).
+// (Not for the Delta_1 loads of the final kernel: +2 % there.)
+#ifndef DSX_NT
+#define DSX_NT 1
+#endif
+#ifndef DSX_MEDIAN_BALLOT
+#define DSX_MEDIAN_BALLOT 1
+#endif
+#ifndef DSX_FWD_STEADY
+#define DSX_FWD_STEADY 1  // bit 0: steady-state row loop in interior strips, bit 1: in edge strips too (spills)
+#endif
+#ifndef DSX_FWD_MINW
+#define DSX_FWD_MINW 4  // waves per SIMD the fused uint16 forward kernel is compiled for (register cap 128)
+#endif
+
 
 namespace dsx {
 
@@ -42,6 +61,16 @@ constexpr int kWave = 64;
 typedef unsigned dsx_u32x2 __attribute__((ext_vector_type(2)));
 typedef float dsx_f2 __attribute__((ext_vector_type(2)));  // arithmetic on these is packed FP32 (v_pk_fma_f32 ...)
 typedef float dsx_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned dsx_u32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer resource over [p, p + 4 GB): the marching kernels address rows as "descriptor (SGPRs) + wave-uniform row
+// offset (one SGPR) + per-lane byte offset (one VGPR)".  With plain pointers the compiler hoists "base + lane offset"
+// out of the row loop as a 64-bit VGPR pair per stream and adds the row offset with 64-bit vector adds -- registers
+// and issue slots the loop does not have.  (word 3 = 0x00020000: 32-bit data format, no swizzle, gfx9 layout.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dsx_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, -1, 0x00020000);
+}
+constexpr int kBufNT = 2;  // aux bits of a streaming (non-temporal) buffer access on gfx94x / gfx950
 
 // Packed multiply-add with a FIXED evaluation order.  (a * b + c * d + e * f written with operators leaves
 // the choice of which product is rounded first to the compiler, and two inlined copies of one expression --
@@ -220,22 +249,43 @@ __device__ __forceinline__ MarchCol march_col(int gc0, int W, int ld, int w_out,
   return c;
 }
 
+// Source rows of a wave: pointer for the element-wise path, buffer descriptor + lane byte offset for FAST waves.
+// rs is based BIAS elements before src (aa_{l-1} rows carry 4 margin columns on the left, c.base >= -4), so
+// that the lane offset is unsigned.
+template <int IN_KIND>
+struct MarchSrc {
+  static constexpr int ES = (IN_KIND == 0) ? 2 : 4;
+  static constexpr int BIAS = (IN_KIND == 2) ? 4 : 0;
+  const void* src;
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned voff;
+  __device__ __forceinline__ MarchSrc(const void* p, const MarchCol& c)
+      : src(p), rs(dsx_rsrc((const char*)p - BIAS * ES)), voff((unsigned)(c.base + BIAS) * ES) {}
+  // one row of a FAST wave; soff = row * pitch in bytes (wave-uniform)
+  __device__ __forceinline__ MarchRaw load(unsigned soff) const {
+    MarchRaw r;
+    if (IN_KIND == 0) {
+      const dsx_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+      r.f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+    } else {
+      const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+      r.f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+    }
+    return r;
+  }
+};
+
 // Issue the loads of one row (prefetch).  all_vec (wave-uniform): every lane of the wave is either
 // vector-loadable or dead, so the load is unconditional and branch-free (a per-lane branch around
 // a prefetch load makes the compiler drain it before the other path may write the registers).
 template <int IN_KIND, bool FAST>
-__device__ __forceinline__ MarchRaw march_issue(const void* src, int ld, int H, int gr_raw, const MarchCol& c) {
+__device__ __forceinline__ MarchRaw march_issue(const MarchSrc<IN_KIND>& ms, int ld, int H, int gr_raw,
+                                                const MarchCol& c) {
   MarchRaw r;
+  if (FAST)  // every lane of the wave is vector-loadable (or dead, with a valid dummy address)
+    return ms.load((unsigned)(reflect_idx(gr_raw, H) * ld) * MarchSrc<IN_KIND>::ES);
+  const void* src = ms.src;
   const long long row = (long long)reflect_idx(gr_raw, H) * ld;
-  if (FAST) {  // every lane of the wave is vector-loadable (or dead, with a valid dummy address)
-    if (IN_KIND == 0) {
-      const uint2 u = *(const uint2*)((const uint16_t*)src + row + c.base);
-      r.f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
-    } else {
-      r.f = *(const float4*)((const float*)src + row + c.base);
-    }
-    return r;
-  }
   r.f = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c.dead) return r;
   if (IN_KIND == 0) {
@@ -258,42 +308,31 @@ __device__ __forceinline__ MarchRaw march_issue(const void* src, int ld, int H, 
 }
 
 // Six consecutive raw rows g0 .. g0+5 (one prefetch group) of a FAST wave.  Interior groups -- all but the
-// first / last of a plane -- take one 64-bit row address per group and add the pitch per row, with the
-// lane's byte offset as a 32-bit vector offset on a wave-uniform base (global_load ... saddr): the row
-// index arithmetic (symmetric reflection = an integer division on the scalar unit, 64-bit multiplies)
-// was as many scalar instructions per step as the kernel has vector ones.
+// first / last of a plane -- take one row offset per group and add the pitch per row: the row index arithmetic
+// (symmetric reflection = an integer division on the scalar unit) was as many scalar instructions per step as
+// the kernel has vector ones.
 template <int IN_KIND>
-__device__ __forceinline__ void march_issue6(const void* src, int ld, int H, int g0, const MarchCol& c,
+__device__ __forceinline__ void march_issue6(const MarchSrc<IN_KIND>& ms, int ld, int H, int g0, const MarchCol& c,
                                              MarchRaw (&out)[6]) {
-  constexpr int ES = (IN_KIND == 0) ? 2 : 4;
-  // aa_{l-1} rows carry 4 margin columns on the left (c.base >= -4): the bias keeps the lane offset unsigned
-  constexpr int BIAS = (IN_KIND == 2) ? 4 : 0;
-  const unsigned lane_off = (unsigned)(c.base + BIAS) * ES;
+  constexpr int ES = MarchSrc<IN_KIND>::ES;
   if (g0 >= 0 && g0 + 5 < H) {  // wave-uniform
-    const char* p = (const char*)src + ((long long)g0 * ld - BIAS) * ES;
-    const long long pitch = (long long)ld * ES;
+    const unsigned pitch = (unsigned)ld * ES;
+    unsigned soff = (unsigned)g0 * pitch;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const char* q = p + r * pitch;
-      if (IN_KIND == 0) {
-        const uint2 u = *(const uint2*)(q + lane_off);
-        out[r].f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
-      } else {
-        out[r].f = *(const float4*)(q + lane_off);
-      }
-    }
+    for (int r = 0; r < 6; ++r, soff += pitch) out[r] = ms.load(soff);
   } else {
 #pragma unroll
-    for (int r = 0; r < 6; ++r) out[r] = march_issue<IN_KIND, true>(src, ld, H, g0 + r, c);
+    for (int r = 0; r < 6; ++r) out[r] = march_issue<IN_KIND, true>(ms, ld, H, g0 + r, c);
   }
 }
 
 // Convert a raw row.  Pixel planes: fg/bg statistic on owned pixels, then log2(1 + x) with the bare
 // v_log_f32 (inputs are >= 1; the ln 2 factor is folded into the axis-0 filter taps).  aa_{l-1}: identity.
-template <int IN_KIND>
+template <int IN_KIND, bool INSIDE = false>
 __device__ __forceinline__ void march_consume(const Fwd1Args& a, const MarchRaw& r, int gr_raw, const MarchCol& c,
                                               bool row_in_seg, bool any_rev, MarchStats<IN_KIND>& st,
                                               float (&x)[4]) {
+  // INSIDE: the caller knows 0 <= gr_raw < H (steady-state rows of the fused kernel)
   if (IN_KIND == 0) {
     unsigned u0 = __float_as_uint(r.f.x), u1 = __float_as_uint(r.f.y);
     if (any_rev) {  // wave-uniform (scalar branch): only edge strips hold mirrored groups
@@ -303,7 +342,7 @@ __device__ __forceinline__ void march_consume(const Fwd1Args& a, const MarchRaw&
         u1 = (t >> 16) | (t << 16);
       }
     }
-    if (row_in_seg && gr_raw >= 0 && gr_raw < a.H) {  // wave-uniform: this row is accounted by this segment
+    if (row_in_seg && (INSIDE || (gr_raw >= 0 && gr_raw < a.H))) {  // wave-uniform: this row is accounted by this segment
       // ownership per element as AND masks (zeroed pixels add nothing and are below the cut-off)
       const unsigned o0 = u0 & c.own_mask[0], o1 = u1 & c.own_mask[1];
       // sum of the four pixels by two SADs against zero; foreground pixels (>= 384) are rare: a packed
@@ -337,7 +376,7 @@ __device__ __forceinline__ void march_consume(const Fwd1Args& a, const MarchRaw&
     x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
     return;
   }
-  const bool own_row = row_in_seg && c.own && gr_raw >= 0 && gr_raw < a.H;
+  const bool own_row = row_in_seg && c.own && (INSIDE || (gr_raw >= 0 && gr_raw < a.H));
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     if (own_row && c.gc0 + e >= 0 && c.gc0 + e < a.W) st.add(v[e], a.fg_cutoff);
@@ -369,11 +408,15 @@ __device__ __forceinline__ FuseGeom fuse_geom(const Fwd1Args& a, int strip) {
   return g;
 }
 
-template <int IN_KIND, bool FAST, bool FUSE>
+// EDGE = false (fused kernel only): the strip touches neither plane edge and is not the (shifted) last one -- no
+// mirrored column groups, no margin columns to write, every level-1 / level-2 column of the wave exists, and the
+// ownership ranges start and end on even columns.  The row loop of such a strip has no per-lane branches left.
+template <int IN_KIND, bool FAST, bool FUSE, bool EDGE = true>
 __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)[2][2][kMarchCols / 2],
                                                float (*s_ring)[kRingRows][kRingPitch], float2 (*s_x2)[kX2Pitch],
                                                int lane, int wave, int strip, int seg, int plane,
-                                               const MarchCol& col, bool any_rev) {
+                                               const MarchCol& col, bool any_rev_in) {
+  const bool any_rev = EDGE && any_rev_in;
   constexpr float LO[6] = DSX_DEC_LO;
   constexpr float HI[6] = DSX_DEC_HI;
   // pixel planes enter as log2(1 + x): the axis-0 taps carry the factor ln 2
@@ -388,6 +431,10 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   const int i_begin = FUSE ? max(0, 2 * i2b - 4) : seg * a.rows_per_seg;
   const int i_end = FUSE ? min(a.h, 2 * i2e) : min(a.h, i_begin + a.rows_per_seg);
   const int own_row_lo = FUSE ? 2 * i2b : i_begin;
+  // steady-state level-1 rows [steady_lo, steady_hi): owned, raw rows 2i, 2i+1 inside the plane, level-2 source rows
+  // 2 i2 - 4 .. 2 i2 + 1 all present without reflection
+  const int steady_lo = max(own_row_lo, 6);
+  const int steady_hi = min(min(i_end, a.h - 2), (a.H - 2) >> 1);
   const int j0 = FUSE ? fg.j0 : kMarchOut * strip;
   int next2 = i2b;  // next level-2 row to emit
   float q2min = __builtin_huge_valf(), q2max = 0.f;
@@ -397,8 +444,11 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   if (IN_KIND == 0) src = (const uint16_t*)a.in + plane * a.in_plane_stride;
   else if (IN_KIND == 1) src = (const float*)a.in + plane * a.in_plane_stride;
   else src = a.ws + plane * a.ws_plane_stride + a.in_off;
+  const MarchSrc<IN_KIND> ms(src, col);
   float* aa = a.ws + plane * a.ws_plane_stride + a.aa_off;
   float* da = a.ws + plane * a.ws_plane_stride + a.da_off;
+  // fused kernel: coefficient rows are stored through buffer descriptors (row offset in an SGPR)
+  const __amdgpu_buffer_rsrc_t rs_da = dsx_rsrc(da), rs_aa2 = dsx_rsrc(aa2), rs_da2 = dsx_rsrc(da2);
   float2* sE[2] = {(float2*)s_row[wave][0][0], (float2*)s_row[wave][1][0]};
   float2* sO[2] = {(float2*)s_row[wave][0][1], (float2*)s_row[wave][1][1]};
 
@@ -408,7 +458,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   {
     MarchRaw pr[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pr[r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * i_begin - 4 + r, col);
+    for (int r = 0; r < 4; ++r) pr[r] = march_issue<IN_KIND, FAST>(ms, a.ldin, a.H, 2 * i_begin - 4 + r, col);
 #pragma unroll
     for (int r = 0; r < 4; ++r) march_consume<IN_KIND>(a, pr[r], 2 * i_begin - 4 + r, col, false, any_rev, st, win[r]);
   }
@@ -416,32 +466,34 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   float qmin = __builtin_huge_valf(), qmax = 0.f;
   const int jj0 = 2 * lane;  // this lane's two output columns (lanes 0..62)
   const bool out_lane = lane < kMarchOut / 2;
-  const bool edge_strip = (j0 <= 0) || (j0 + kMarchOut >= a.w - 8);
+  const bool edge_strip = EDGE && ((j0 <= 0) || (j0 + kMarchOut >= a.w - 8));
 
   // FUSE: everything about a lane's columns is loop-invariant -- predicates and byte offsets are taken
   // once, so that the row loop carries no per-iteration compares and its stores are "uniform row base +
   // 32-bit lane offset" (no 64-bit vector address arithmetic)
   const int jl = j0 + jj0;                                   // level-1 columns jl, jl + 1 of this lane
-  const bool c_v0 = FUSE && jl >= 0 && jl < a.w, c_v1 = FUSE && jl + 1 >= 0 && jl + 1 < a.w;
+  const bool c_v0 = FUSE && (!EDGE || (jl >= 0 && jl < a.w)), c_v1 = FUSE && (!EDGE || (jl + 1 >= 0 && jl + 1 < a.w));
   const bool c_s0 = FUSE && out_lane && jl >= fg.own1_lo && jl < fg.own1_hi;
-  const bool c_s1 = FUSE && out_lane && jl + 1 >= fg.own1_lo && jl + 1 < fg.own1_hi;
+  const bool c_s1 = EDGE ? (FUSE && out_lane && jl + 1 >= fg.own1_lo && jl + 1 < fg.own1_hi) : c_s0;
   const unsigned off_da = (unsigned)max(jl, 0) * 4u;
   const int jo2 = fg.o2 + lane;                              // level-2 column of this lane
-  const bool l2_valid = FUSE && lane < kFuseOut && jo2 < a.w2;
+  const bool l2_valid = FUSE && lane < kFuseOut && (!EDGE || jo2 < a.w2);
   const bool l2_store = l2_valid && jo2 >= fg.own2_lo;
-  const bool l2_edge = FUSE && (fg.o2 == 0 || fg.o2 + kFuseOut >= a.w2 - 8);  // wave-uniform
+  const bool l2_edge = FUSE && EDGE && (fg.o2 == 0 || fg.o2 + kFuseOut >= a.w2 - 8);  // wave-uniform
   const unsigned off_2 = (unsigned)jo2 * 4u;
 
   // ---- FUSE: one level-2 row from the aa_1 ring (rows 2 i2 - 4 .. 2 i2 + 1, half-sample symmetric) ----
-  auto l2_step = [&](int i2) {
+  // steady_c (std::true_type): all six source rows exist (2 i2 - 4 >= 0, 2 i2 + 1 < h)
+  auto l2_step = [&](auto steady_c, int i2) {
+    constexpr bool STEADY = decltype(steady_c)::value;
     dsx_f2 c[6];
 #if DSX_DPP_X
-    wave_sync();  // edge strips: the ring's mirrored columns were written by other lanes
+    if (EDGE) wave_sync();  // edge strips: the ring's mirrored columns were written by other lanes
 #endif
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       int r = 2 * i2 - 4 + k;
-      r = r < 0 ? -1 - r : (r >= a.h ? 2 * a.h - 1 - r : r);
+      if (!STEADY) r = r < 0 ? -1 - r : (r >= a.h ? 2 * a.h - 1 - r : r);
       c[k] = *(const dsx_f2*)&s_ring[wave][r & (kRingRows - 1)][jj0];
     }
     // axis 0: out = sum_k f[k] x[2 i2 + 1 - k] = sum_k f[k] c[5 - k]; both columns of the lane at once
@@ -477,22 +529,25 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     q2min = fminf(q2min, l2_valid ? q : __builtin_huge_valf());
     q2max = fmaxf(q2max, l2_valid ? q : 0.f);
     if (l2_store && !(a.ablate & 16)) {
-      char* arow = (char*)(aa2 + (long long)i2 * a.lda2);
-      *(float*)(arow + off_2) = v.x;
-      *(float*)((char*)(da2 + (long long)i2 * a.ld2) + off_2) = v.y;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rs_aa2, off_2, (unsigned)(i2 * a.lda2) * 4u, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rs_da2, off_2, (unsigned)(i2 * a.ld2) * 4u, 0);
       if (l2_edge) {  // extension margins of aa_2, read by the next level's aligned vector loads
-        if (jo2 < 4) ((float*)arow)[-1 - jo2] = v.x;
-        if (jo2 >= a.w2 - 8) ((float*)arow)[2 * a.w2 - 1 - jo2] = v.x;
+        float* arow = aa2 + (long long)i2 * a.lda2;
+        if (jo2 < 4) arow[-1 - jo2] = v.x;
+        if (jo2 >= a.w2 - 8) arow[2 * a.w2 - 1 - jo2] = v.x;
       }
     }
   };
 
   // One output row i: the raw rows 2i, 2i+1 become window slots (r4, r5); r0..r5 = oldest..newest.
-  auto step = [&](int i, const MarchRaw& raw0, const MarchRaw& raw1, float (&r0)[4], float (&r1)[4],
+  // steady_c (std::true_type, fused kernel): the row is owned by the segment, its raw rows lie inside the plane,
+  // and exactly the level-2 row (i - 1) / 2 becomes complete at odd i -- none of that is tested again
+  auto step = [&](auto steady_c, int i, const MarchRaw& raw0, const MarchRaw& raw1, float (&r0)[4], float (&r1)[4],
                   float (&r2)[4], float (&r3)[4], float (&r4)[4], float (&r5)[4]) {
-    const bool own_row = !FUSE || i >= own_row_lo;  // wave-uniform
-    march_consume<IN_KIND>(a, raw0, 2 * i, col, own_row, any_rev, st, r4);
-    march_consume<IN_KIND>(a, raw1, 2 * i + 1, col, own_row, any_rev, st, r5);
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const bool own_row = STEADY || !FUSE || i >= own_row_lo;  // wave-uniform
+    march_consume<IN_KIND, STEADY>(a, raw0, 2 * i, col, own_row, any_rev, st, r4);
+    march_consume<IN_KIND, STEADY>(a, raw1, 2 * i + 1, col, own_row, any_rev, st, r5);
     // axis 0: out = sum_k f[k] * x[2i + 1 - k] = sum_k f[k] * r(5 - k)
     float lo[4], hi[4];
 #pragma unroll
@@ -569,17 +624,14 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
         const int j = jl;
         const float q0 = res[1][0] * res[1][0], q1 = res[1][1] * res[1][1];
         if (own_row && !(a.ablate & 16)) {  // da_1: owned rows and columns only (overlap rows / columns belong to a neighbour)
-          char* drow = (char*)(da + (long long)i * a.ld);
+          const unsigned soff = (unsigned)(i * a.ld) * 4u;
+          constexpr int aux = DSX_NT ? kBufNT : 0;
           if (c_s0 && c_s1) {
-#if DSX_NT
-            const dsx_f2 dv = {res[1][0], res[1][1]};
-            __builtin_nontemporal_store(dv, (dsx_f2*)(drow + off_da));
-#else
-            *(float2*)(drow + off_da) = make_float2(res[1][0], res[1][1]);
-#endif
+            const dsx_u32x2 dv = {__float_as_uint(res[1][0]), __float_as_uint(res[1][1])};
+            __builtin_amdgcn_raw_buffer_store_b64(dv, rs_da, off_da, soff, aux);
           } else {
-            if (c_s0) *(float*)(drow + off_da) = res[1][0];
-            if (c_s1) *(float*)(drow + off_da + 4) = res[1][1];
+            if (c_s0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[1][0]), rs_da, off_da, soff, aux);
+            if (c_s1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[1][1]), rs_da, off_da + 4u, soff, aux);
           }
         }
         qmin = fminf(qmin, fminf(c_v0 ? q0 : __builtin_huge_valf(), c_v1 ? q1 : __builtin_huge_valf()));
@@ -603,11 +655,18 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
         }
       }
       // level-2 rows whose six source rows are now in the ring (top rows need reflected row 3)
-      while (next2 < i2e) {
-        const int need = min(max(2 * next2 + 1, 3 - 2 * next2), a.h - 1);
-        if (need > i) break;
-        l2_step(next2);
-        ++next2;
+      if (STEADY) {
+        if (2 * next2 + 1 <= i) {
+          l2_step(std::true_type(), next2);
+          ++next2;
+        }
+      } else {
+        while (next2 < i2e) {
+          const int need = min(max(2 * next2 + 1, 3 - 2 * next2), a.h - 1);
+          if (need > i) break;
+          l2_step(std::false_type(), next2);
+          ++next2;
+        }
       }
     } else
     if (out_lane) {
@@ -652,11 +711,11 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) {
     if (FAST) {
-      march_issue6<IN_KIND>(src, a.ldin, a.H, 2 * (i_begin + 3 * d), col, nxt[d]);
+      march_issue6<IN_KIND>(ms, a.ldin, a.H, 2 * (i_begin + 3 * d), col, nxt[d]);
     } else {
 #pragma unroll
       for (int r = 0; r < 6; ++r)
-        nxt[d][r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * (i_begin + 3 * d) + r, col);
+        nxt[d][r] = march_issue<IN_KIND, FAST>(ms, a.ldin, a.H, 2 * (i_begin + 3 * d) + r, col);
     }
   }
   for (int i = i_begin; i < i_end; i += 3) {
@@ -669,16 +728,22 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
       for (int r = 0; r < 6; ++r) nxt[d][r] = nxt[d + 1][r];
     if (i + 3 * DEPTH < i_end) {
       if (FAST) {
-        march_issue6<IN_KIND>(src, a.ldin, a.H, 2 * (i + 3 * DEPTH), col, nxt[DEPTH - 1]);
+        march_issue6<IN_KIND>(ms, a.ldin, a.H, 2 * (i + 3 * DEPTH), col, nxt[DEPTH - 1]);
       } else {
 #pragma unroll
         for (int r = 0; r < 6; ++r)
-          nxt[DEPTH - 1][r] = march_issue<IN_KIND, FAST>(src, a.ldin, a.H, 2 * (i + 3 * DEPTH) + r, col);
+          nxt[DEPTH - 1][r] = march_issue<IN_KIND, FAST>(ms, a.ldin, a.H, 2 * (i + 3 * DEPTH) + r, col);
       }
     }
-    step(i, cur[0], cur[1], win[0], win[1], win[2], win[3], win[4], win[5]);
-    if (i + 1 < i_end) step(i + 1, cur[2], cur[3], win[2], win[3], win[4], win[5], win[0], win[1]);
-    if (i + 2 < i_end) step(i + 2, cur[4], cur[5], win[4], win[5], win[0], win[1], win[2], win[3]);
+    if (FUSE && DSX_FWD_STEADY && (EDGE ? (DSX_FWD_STEADY & 2) != 0 : true) && i >= steady_lo && i + 3 <= steady_hi) {  // wave-uniform
+      step(std::true_type(), i, cur[0], cur[1], win[0], win[1], win[2], win[3], win[4], win[5]);
+      step(std::true_type(), i + 1, cur[2], cur[3], win[2], win[3], win[4], win[5], win[0], win[1]);
+      step(std::true_type(), i + 2, cur[4], cur[5], win[4], win[5], win[0], win[1], win[2], win[3]);
+    } else {
+      step(std::false_type(), i, cur[0], cur[1], win[0], win[1], win[2], win[3], win[4], win[5]);
+      if (i + 1 < i_end) step(std::false_type(), i + 1, cur[2], cur[3], win[2], win[3], win[4], win[5], win[0], win[1]);
+      if (i + 2 < i_end) step(std::false_type(), i + 2, cur[4], cur[5], win[4], win[5], win[0], win[1], win[2], win[3]);
+    }
   }
 
   qmin = wave_min_f32(qmin);
@@ -721,25 +786,9 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
 }
 
 // IN_KIND: 0 = uint16 pixels (log + statistic fused), 1 = float32 pixels (same), 2 = float32 aa_{l-1}
-// DSX_FWD_BOUNDS / DSX_INV_BOUNDS: build-time experiment hooks (tools/build_variant.sh), e.g. -DDSX_FWD_BOUNDS=256,4
-// Streaming (non-temporal) accesses for intermediates that the next kernel reads only after hundreds of MB of
-// other traffic (da_1 out of the forward kernel, cH into the histogram, Delta out of the row filter):
-// measured -5 % / -10 % / -1 % on those kernels.  (Not for the Delta_1 loads of the final kernel: +2 % there.)
-#ifndef DSX_NT
-#define DSX_NT 1
-#endif
-#ifndef DSX_MEDIAN_BALLOT
-#define DSX_MEDIAN_BALLOT 1
-#endif
-#ifndef DSX_FWD_BOUNDS
-#define DSX_FWD_BOUNDS 256
-#endif
-#ifndef DSX_INV_BOUNDS
-#define DSX_INV_BOUNDS 256
-#endif
 // WPB: waves per block (consecutive strips of one row segment: a block reads WPB x 512 contiguous bytes per row)
 template <int IN_KIND, bool FUSE = false, int WPB = 4>
-__global__ __launch_bounds__(64 * WPB) void k_fwd_march(Fwd1Args a) {
+__global__ __launch_bounds__(64 * WPB, (FUSE && IN_KIND == 0) ? DSX_FWD_MINW : 1) void k_fwd_march(Fwd1Args a) {
   __shared__ __attribute__((aligned(16))) float s_row[WPB][2][2][kMarchCols / 2];  // [wave][lo|hi][parity][col/2]
   __shared__ __attribute__((aligned(16))) float s_ring[FUSE ? WPB : 1][kRingRows][FUSE ? kRingPitch : 4];
   __shared__ __attribute__((aligned(16))) float2 s_x2[FUSE ? WPB : 1][FUSE ? kX2Pitch : 2];
@@ -759,8 +808,15 @@ __global__ __launch_bounds__(64 * WPB) void k_fwd_march(Fwd1Args a) {
     MarchCol col = march_col(gc0, a.W, a.ldin, a.w, owns, false);
     if (!col.vec) { col.dead = true; col.base = 0; col.rev = false; }  // left of the mirrored region: feeds nothing valid
     const bool any_rev = __any(col.rev) != 0;
-    fwd_march_body<IN_KIND, true, true>(a, s_row, (float (*)[kRingRows][kRingPitch])s_ring,
-                                        (float2 (*)[kX2Pitch])s_x2, lane, wave, strip, seg, plane, col, any_rev);
+    // interior strip (wave-uniform): see fwd_march_body, EDGE = false
+    const bool interior = strip > 0 && strip < a.nstrips - 1 && fg.j0 > 0 && fg.j0 + kMarchOut + 2 < a.w - 8 &&
+                          fg.o2 + kFuseOut < a.w2 - 8 && __all(col.vec && !col.rev && !col.dead) != 0;
+    if (interior)
+      fwd_march_body<IN_KIND, true, true, false>(a, s_row, (float (*)[kRingRows][kRingPitch])s_ring,
+                                                 (float2 (*)[kX2Pitch])s_x2, lane, wave, strip, seg, plane, col, false);
+    else
+      fwd_march_body<IN_KIND, true, true, true>(a, s_row, (float (*)[kRingRows][kRingPitch])s_ring,
+                                                (float2 (*)[kX2Pitch])s_x2, lane, wave, strip, seg, plane, col, any_rev);
     return;
   }
   // lane 0 re-reads the last 4 columns of the previous strip and does not account them
