@@ -624,9 +624,19 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
   c->device = device;
   if (const char* ab = getenv("DSX_ABLATE")) c->ablate = atoi(ab);
   if (const char* ns = getenv("DSX_STREAMS")) c->n_streams = std::max(1, std::min(atoi(ns), (int)dsx_ctx::kMaxStreams));
-  e = hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking);
+  // DSX_PRIO=p0,p1,...: stream priority per sub-cohort stream (experiment hook; default: all equal)
+  int prio[dsx_ctx::kMaxStreams] = {};
+  if (const char* pr = getenv("DSX_PRIO")) {
+    int i = 0;
+    for (const char* q = pr; *q && i < dsx_ctx::kMaxStreams; ++i) {
+      prio[i] = atoi(q);
+      while (*q && *q != ',') ++q;
+      if (*q == ',') ++q;
+    }
+  }
+  e = hipStreamCreateWithPriority(&c->stream_, hipStreamNonBlocking, prio[0]);
   for (int i = 1; i < dsx_ctx::kMaxStreams && e == hipSuccess; ++i) {
-    e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+    e = hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio[i]);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);

@@ -1,7 +1,10 @@
 #!/bin/bash
-# sub-cohort streams sweep of the headline bench
-for S in 1 2 3 4 5 6 8; do
-  DSX_STREAMS=$S python bench.py --cpu-planes 0 --steps 6 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); print('streams', $S, 'value', d['value'], 'ms', d['ms_per_step'])"
+# headline bench against the number of sub-cohort streams and the batch size
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/${1:-sweep}_streams.txt; : > $OUT
+for b in 256 512; do
+  for s in 2 3 4 6 8; do
+    r=$(DSX_STREAMS=$s python bench.py --batch $b --cohort $b --steps $((25600 / b)) --warmup 10 --cpu-planes 0 --settle 0 --no-verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+    echo "batch=$b streams=$s $r" | tee -a $OUT
+  done
 done
