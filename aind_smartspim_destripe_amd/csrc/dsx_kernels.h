@@ -33,6 +33,9 @@
 #ifndef DSX_FWD_STEADY
 #define DSX_FWD_STEADY 1  // bit 0: steady-state row loop in interior strips, bit 1: in edge strips too (spills)
 #endif
+#ifndef DSX_INV_MINW
+#define DSX_INV_MINW 4  // waves per SIMD the fused uint16 final kernel is compiled for
+#endif
 #ifndef DSX_FWD_MINW
 #define DSX_FWD_MINW 4  // waves per SIMD the fused uint16 forward kernel is compiled for (register cap 128)
 #endif
@@ -1732,7 +1735,20 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
   const bool vec_out = ((out_pitch & 3) == 0) && ((IN_KIND == 2) ? (x0 + 3 < a.wout + 8) : (x0 + 3 < a.wout));
   const long long img_plane = plane * a.img_plane_stride;
   // flat / dark rows as aligned float4 loads when the pitches and base addresses allow it (wave-uniform)
+  // FAST waves address rows through buffer descriptors: wave-uniform row offset + 32-bit lane offset (see dsx_rsrc)
+  const __amdgpu_buffer_rsrc_t rs_c = dsx_rsrc(cbase), rs_d = dsx_rsrc(dbase);
+  const unsigned vo_c = (unsigned)q * 4u, vo_d = (unsigned)ql * 4u;
+  const int out_es = (a.out_dtype == 0) ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t rs_out =
+      dsx_rsrc(IN_KIND == 2 ? (const char*)(a.ws_out + plane * a.ws_plane_stride + a.out_off)
+                            : (const char*)a.out + plane * a.out_plane_stride * out_es);
+  const unsigned vo_out = (unsigned)x0 * (IN_KIND == 2 ? 4u : (unsigned)out_es);
+  constexpr int IES = (IN_KIND == 0) ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t rs_img = dsx_rsrc(IN_KIND == 2 ? (const char*)a.ws : (const char*)a.img + img_plane * IES);
+  const unsigned vo_img = (unsigned)xl * IES;
   const int xs = min(x0, max(a.wout - 4, 0));
+  const __amdgpu_buffer_rsrc_t rs_dark = dsx_rsrc(SHADE ? a.dark : a.ws), rs_flat = dsx_rsrc(SHADE ? a.flat : a.ws);
+  const unsigned vo_shade = (unsigned)xs * 4u;
   const bool shade_vec = SHADE && (a.wout & 3) == 0 && (a.dark_ld & 3) == 0 && a.wout >= 4 &&
                          (((uintptr_t)a.dark | (uintptr_t)a.flat) & 15) == 0;
 
@@ -1743,6 +1759,8 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
   const bool l2_lane = FUSE && lane < 33 && (kMarchCols / 2) * strip + 4 * lane < a.wc + 4;
   const float* c2base = FUSE ? a.ws + plane * a.ws_plane_stride + a.c2_off : nullptr;
   const float* d2base = FUSE ? a.ws + plane * a.ws_plane_stride + a.d2_off : nullptr;
+  const __amdgpu_buffer_rsrc_t rs_c2 = dsx_rsrc(FUSE ? c2base : a.ws), rs_d2 = dsx_rsrc(FUSE ? d2base : a.ws);
+  const unsigned vo_2 = (unsigned)max(q2, 0) * 4u;
   dsx_f2 A2[3][2], D2[3][2];
   FinalRawC n2;
   int next_P = 0, c1_ready = 0;  // c_1 rows < c1_ready are in the ring
@@ -1752,13 +1770,13 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     if (l2_lane) {
       const int pr = min(P2, a.hc2 - 1);  // rows past the end only feed c_1 rows that are never used
       if (a.has_c2) {
-        const long long rc = (long long)pr * a.ldc2 + q2;
-        r.c01 = *(const float2*)(c2base + rc);
-        r.c23 = *(const float2*)(c2base + rc + 2);
+        const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_c2, vo_2, (unsigned)(pr * a.ldc2) * 4u, 0);
+        r.c01 = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+        r.c23 = make_float2(__uint_as_float(u.z), __uint_as_float(u.w));
       }
-      const long long rd = (long long)pr * a.ldd2 + q2;
-      r.d01 = *(const float2*)(d2base + rd);
-      r.d23 = *(const float2*)(d2base + rd + 2);
+      const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_d2, vo_2, (unsigned)(pr * a.ldd2) * 4u, 0);
+      r.d01 = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+      r.d23 = make_float2(__uint_as_float(u.z), __uint_as_float(u.w));
     }
     return r;
   };
@@ -1812,13 +1830,14 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
       const int pr = min(p, a.hc - 1);
       r.c01 = r.c23 = make_float2(0.f, 0.f);
       if (has_c && !FUSE) {  // uniform: the coarsest level has no approximation correction
-        const long long rc = (long long)pr * a.ldc + q;
-        r.c01 = *(const float2*)(cbase + rc);
-        r.c23 = *(const float2*)(cbase + rc + 2);
+        const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_c, vo_c, (unsigned)(pr * a.ldc) * 4u, 0);
+        r.c01 = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+        r.c23 = make_float2(__uint_as_float(u.z), __uint_as_float(u.w));
       }
-      const long long rd = (long long)pr * a.ldd + ql;
-      r.d01 = *(const float2*)(dbase + rd);
-      r.d23 = *(const float2*)(dbase + rd + 2);
+      // one 16-byte access at an 8-byte aligned address (coefficients q .. q+3, q even)
+      const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_d, vo_d, (unsigned)(pr * a.ldd) * 4u, 0);
+      r.d01 = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+      r.d23 = make_float2(__uint_as_float(u.z), __uint_as_float(u.w));
       return r;
     }
     final_coeff_row(a, cbase, a.ldc, p, q, has_c, vec_c, r.c01, r.c23);
@@ -1827,6 +1846,9 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
   };
   const bool odd_lane = (lane & 1) != 0;
   const int xb = min(kMarchCols * strip + 8 * (lane >> 1), a.W - 8);  // PAIR: first column of the lane pair (clamped)
+  // PAIR lane offsets: the odd lane of a pair takes the row below (pixels) / stores the row below (results)
+  const unsigned vo_pair0 = (unsigned)xb * 2u, vo_pair = vo_pair0 + (odd_lane ? (unsigned)a.W * 2u : 0u);
+  const unsigned vo_pair_out = (unsigned)xb * 2u + (odd_lane ? (unsigned)a.wout * 2u : 0u);
   auto issue_i = [&](int gy) {
     FinalRawI<IN_KIND> r;
     r.u = make_uint2(0u, 0u);
@@ -1834,14 +1856,23 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     r.q = make_uint4(0u, 0u, 0u, 0u);
     if (PAIR) {
       if ((gy & 1) == 0) {  // one load per row pair, issued with the even row
-        typedef unsigned dsx_u32x4 __attribute__((ext_vector_type(4)));
-        const long long off = img_plane + (long long)min(gy + (odd_lane ? 1 : 0), a.H - 1) * a.W + xb;
-        const dsx_u32x4 u = __builtin_nontemporal_load((const dsx_u32x4*)((const uint16_t*)a.img + off));
+        const int ge = min(gy, a.H - 1);                       // wave-uniform
+        const unsigned vo = (ge + 1 < a.H) ? vo_pair : vo_pair0;  // the odd lane's row exists (scalar condition)
+        const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_img, vo, (unsigned)(ge * a.W) * 2u, kBufNT);
         r.q = make_uint4(u.x, u.y, u.z, u.w);
       }
       return r;
     }
-    if (IN_KIND != 2 && (FAST || vec_in)) {
+    if (IN_KIND != 2 && FAST) {
+      const unsigned so = (unsigned)(min(gy, a.H - 1) * a.W) * IES;
+      if (IN_KIND == 0) {
+        const dsx_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rs_img, vo_img, so, kBufNT);
+        r.u = make_uint2(u.x, u.y);
+      } else {
+        const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_img, vo_img, so, 0);
+        r.f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+      }
+    } else if (IN_KIND != 2 && vec_in) {
       const long long off = img_plane + (long long)min(gy, a.H - 1) * a.W + xl;
       if (IN_KIND == 0) {
         const dsx_u32x2 u = __builtin_nontemporal_load((const dsx_u32x2*)((const uint16_t*)a.img + off));
@@ -1871,7 +1902,8 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     if (IN_KIND == 2) {
       float* dst = a.ws_out + plane * a.ws_plane_stride + a.out_off + (long long)gy * a.ldout + x0;
       if (vec_out) {
-        *(float4*)dst = make_float4(c0[0], c0[1], c0[2], c0[3]);
+        const dsx_u32x4 o4 = {__float_as_uint(c0[0]), __float_as_uint(c0[1]), __float_as_uint(c0[2]), __float_as_uint(c0[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(o4, rs_out, vo_out, (unsigned)(gy * a.ldout) * 4u, 0);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -1899,10 +1931,10 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     float dk[4] = {0.f, 0.f, 0.f, 0.f}, fl[4] = {1.f, 1.f, 1.f, 1.f};
     if (SHADE) {
       if (shade_vec) {  // one 16-byte load per plane and lane (clamped address for lanes right of the plane)
-        const float4 d4 = *(const float4*)(a.dark + (long long)gy * a.dark_ld + xs);
-        const float4 f4 = *(const float4*)(a.flat + (long long)gy * a.wout + xs);
-        dk[0] = d4.x; dk[1] = d4.y; dk[2] = d4.z; dk[3] = d4.w;
-        fl[0] = f4.x; fl[1] = f4.y; fl[2] = f4.z; fl[3] = f4.w;
+        const dsx_u32x4 d4 = __builtin_amdgcn_raw_buffer_load_b128(rs_dark, vo_shade, (unsigned)(gy * a.dark_ld) * 4u, 0);
+        const dsx_u32x4 f4 = __builtin_amdgcn_raw_buffer_load_b128(rs_flat, vo_shade, (unsigned)(gy * a.wout) * 4u, 0);
+        dk[0] = __uint_as_float(d4.x); dk[1] = __uint_as_float(d4.y); dk[2] = __uint_as_float(d4.z); dk[3] = __uint_as_float(d4.w);
+        fl[0] = __uint_as_float(f4.x); fl[1] = __uint_as_float(f4.y); fl[2] = __uint_as_float(f4.z); fl[3] = __uint_as_float(f4.w);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1934,7 +1966,8 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
         dsx_u32x2 pk;
         pk.x = u[0] | (u[1] << 16);
         pk.y = u[2] | (u[3] << 16);
-        __builtin_nontemporal_store(pk, (dsx_u32x2*)((uint16_t*)a.out + o));  // written once, not read again here
+        // written once, not read again here
+        __builtin_amdgcn_raw_buffer_store_b64(pk, rs_out, vo_out, (unsigned)(gy * a.wout) * 2u, kBufNT);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -1942,7 +1975,8 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
       }
     } else {
       if (vec_out) {
-        *(float4*)((float*)a.out + o) = make_float4(r[0], r[1], r[2], r[3]);
+        const dsx_u32x4 o4 = {__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(o4, rs_out, vo_out, (unsigned)(gy * a.wout) * 4u, 0);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -1980,17 +2014,14 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
         emit_row(2 * p + 1, r1, odd, &po);
         // even lane stores row 2p: [own | neighbour's] even-row pack; odd lane row 2p + 1: [neighbour's | own]
         const unsigned tx = swap_adjacent(odd_lane ? pe[0] : po[0]), ty = swap_adjacent(odd_lane ? pe[1] : po[1]);
-        typedef unsigned dsx_u32x4 __attribute__((ext_vector_type(4)));
         dsx_u32x4 o4;
         o4.x = odd_lane ? tx : pe[0];
         o4.y = odd_lane ? ty : pe[1];
         o4.z = odd_lane ? po[0] : tx;
         o4.w = odd_lane ? po[1] : ty;
         const int gyl = 2 * p + (odd_lane ? 1 : 0);
-        if (gyl < a.hout && x0 < a.wout) {
-          const long long o = plane * a.out_plane_stride + (long long)gyl * a.wout + xb;
-          __builtin_nontemporal_store(o4, (dsx_u32x4*)((uint16_t*)a.out + o));
-        }
+        if (gyl < a.hout && x0 < a.wout)
+          __builtin_amdgcn_raw_buffer_store_b128(o4, rs_out, vo_pair_out, (unsigned)(2 * p * a.wout) * 2u, kBufNT);
       } else {
         emit_row(2 * p, r0, even);
         emit_row(2 * p + 1, r1, odd);
@@ -2001,9 +2032,11 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     }
   };
 
-  // software prefetch: coefficient rows p+2..p+4 and plane rows 2p..2p+5 of the NEXT group of three
-  // steps are in flight while the current group is synthesised (out-of-range rows load nothing /
-  // a clamped row, their results are never stored)
+  // software prefetch with rotating registers: slot k of (nc, ni) holds coefficient row p+2+k and plane rows
+  // 2(p+k), 2(p+k)+1 of step p+k; as soon as the step has consumed its slot, the slot's loads for the step three
+  // rows further are issued into the same registers.  (A double-buffered "current / next group" scheme keeps the
+  // same three steps in flight with twice the registers -- 24 more, which cost the fourth wave per SIMD.)
+  // Out-of-range rows load a clamped row; their results are never stored.
   FinalRawC nc[3];
   FinalRawI<IN_KIND> ni[6];
 #pragma unroll
@@ -2011,28 +2044,32 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
 #pragma unroll
   for (int r = 0; r < 6; ++r) ni[r] = issue_i(2 * p_begin + r);
   for (int p = p_begin; p < p_end; p += 3) {
-    FinalRawC cc[3];
-    FinalRawI<IN_KIND> ci[6];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) cc[r] = nc[r];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) ci[r] = ni[r];
-    if (p + 3 < p_end) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) nc[r] = issue_c(p + 5 + r);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) ni[r] = issue_i(2 * (p + 3) + r);
+    const bool more = p + 3 < p_end;  // wave-uniform
+    step(p, nc[0], ni[0], ni[1], A[0], A[1], A[2], D[0], D[1], D[2]);
+    if (more) {
+      nc[0] = issue_c(p + 5);
+      ni[0] = issue_i(2 * (p + 3));
+      ni[1] = issue_i(2 * (p + 3) + 1);
     }
-    step(p, cc[0], ci[0], ci[1], A[0], A[1], A[2], D[0], D[1], D[2]);
-    if (p + 1 < p_end) step(p + 1, cc[1], ci[2], ci[3], A[1], A[2], A[0], D[1], D[2], D[0]);
-    if (p + 2 < p_end) step(p + 2, cc[2], ci[4], ci[5], A[2], A[0], A[1], D[2], D[0], D[1]);
+    if (p + 1 < p_end) step(p + 1, nc[1], ni[2], ni[3], A[1], A[2], A[0], D[1], D[2], D[0]);
+    if (more) {
+      nc[1] = issue_c(p + 6);
+      ni[2] = issue_i(2 * (p + 3) + 2);
+      ni[3] = issue_i(2 * (p + 3) + 3);
+    }
+    if (p + 2 < p_end) step(p + 2, nc[2], ni[4], ni[5], A[2], A[0], A[1], D[2], D[0], D[1]);
+    if (more) {
+      nc[2] = issue_c(p + 7);
+      ni[4] = issue_i(2 * (p + 3) + 4);
+      ni[5] = issue_i(2 * (p + 3) + 5);
+    }
   }
 }
 
 // IN_KIND: 0 = last level, uint16 pixels; 1 = last level, float32 pixels;
 //          2 = pyramid level: writes c_{l-1} (float32, hout x wout, pitch ldout) into the workspace
 template <int IN_KIND, bool FUSE = false, int WPB = 4>
-__global__ __launch_bounds__(64 * WPB) void k_inv_march(FinalArgs a) {
+__global__ __launch_bounds__(64 * WPB, (FUSE && IN_KIND == 0) ? DSX_INV_MINW : 1) void k_inv_march(FinalArgs a) {
   __shared__ __attribute__((aligned(16))) float s_c1[FUSE ? WPB : 1][FUSE ? kRingRows : 1][FUSE ? kC1Pitch : 4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps row math on the SALU
