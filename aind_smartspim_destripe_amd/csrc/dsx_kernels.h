@@ -34,7 +34,7 @@
 #define DSX_FWD_STEADY 1  // bit 0: steady-state row loop in interior strips, bit 1: in edge strips too (spills)
 #endif
 #ifndef DSX_INV_MINW
-#define DSX_INV_MINW 4  // waves per SIMD the fused uint16 final kernel is compiled for
+#define DSX_INV_MINW 1  // waves per SIMD the fused uint16 final kernel is compiled for
 #endif
 #ifndef DSX_FWD_MINW
 #define DSX_FWD_MINW 4  // waves per SIMD the fused uint16 forward kernel is compiled for (register cap 128)
