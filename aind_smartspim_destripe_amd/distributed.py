@@ -99,28 +99,73 @@ class RankGroup:
         # DSX_FORCE_COMM=1: build the communicator even for a single rank (rehearsal of the RCCL calls on a
         # one-GPU box)
         self.active = self.world > 1 or os.environ.get("DSX_FORCE_COMM") == "1"
+        # "rccl": collectives over the communicator; "host": the communicator could not be built on at least one
+        # rank and ALL ranks agreed (over the rendezvous) to reduce on the host instead -- the data path has no
+        # collective, so the job still measures what it says, and the bench line carries the flag and the reason
+        self.transport = "rccl" if self.active else "none"
+        self.comm_error = None
+        self._seq = 0
         if self.active:
             self.rdzv = rendezvous or FileRendezvous(self.rank, self.world)
-            if self.rank == 0:
+            # stage 1, no collective: can every rank load RCCL at all?  (ncclGetUniqueId on every rank; rank 0's is
+            # the one that is used.)  A rank that cannot would leave the others blocked inside ncclCommInitRank.
+            uid, status = b"", b"ok"
+            try:
                 uid = engine.comm_unique_id()
-                self.rdzv.put("rccl_unique_id", uid)
-            else:
-                uid = self.rdzv.get("rccl_unique_id")
-            engine.comm_init(uid, self.rank, self.world)  # collective: returns once every rank has joined
+            except Exception as e:  # noqa: BLE001 - whatever the loader raised is the reason we report
+                status = ("failed: {}: {}".format(type(e).__name__, e)).encode()
+            bad = self._agree("preflight", status)
+            # stage 2: the collective init
+            if not bad:
+                try:
+                    if self.rank == 0:
+                        self.rdzv.put("rccl_unique_id", uid)
+                    else:
+                        uid = self.rdzv.get("rccl_unique_id")
+                    engine.comm_init(uid, self.rank, self.world)  # returns once every rank has joined
+                except Exception as e:  # noqa: BLE001
+                    status = ("failed: {}: {}".format(type(e).__name__, e)).encode()
+                bad = self._agree("comm_status", status)
+                if bad and status == b"ok":
+                    engine.comm_destroy()
+            if bad:
+                self.transport = "host"
+                self.comm_error = "rank {}: {}".format(*bad[0])
+
+    def _agree(self, key, status):
+        """Every rank publishes its status under ``key``; returns [(rank, text)] of the ranks that are not ok."""
+        self.rdzv.put("{}.{}".format(key, self.rank), status)
+        statuses = [self.rdzv.get("{}.{}".format(key, r)) for r in range(self.world)]
+        return [(r, st.decode(errors="replace")) for r, st in enumerate(statuses) if st != b"ok"]
 
     @classmethod
     def from_env(cls, engine, rendezvous=None):
         return cls(engine, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), rendezvous)
 
+    def _host_allreduce(self, values, op):
+        """Reduction through the rendezvous directory (transport "host"): every rank publishes its values under
+        the call's sequence number and folds everybody's."""
+        self._seq += 1
+        mine = np.asarray(values, dtype=np.float64)
+        self.rdzv.put("ar.{}.{}".format(self._seq, self.rank), mine.tobytes())
+        rows = [np.frombuffer(self.rdzv.get("ar.{}.{}".format(self._seq, r)), dtype=np.float64)
+                for r in range(self.world)]
+        fold = {"sum": np.sum, "max": np.max, "min": np.min}[op]
+        return [float(v) for v in fold(np.stack(rows), axis=0)]
+
     def allreduce(self, values, op="sum"):
         if not self.active:
             return [float(v) for v in values]
+        if self.transport == "host":
+            return self._host_allreduce(values, op)
         return self.engine.comm_allreduce(values, op)
 
     def barrier(self):
         self.allreduce([0.0])
 
     def broadcast_device(self, d_ptr, nbytes, root=0):
+        if self.transport == "host":
+            raise RuntimeError("no RCCL communicator ({}): device broadcasts are not available".format(self.comm_error))
         if self.active:
             self.engine.comm_broadcast(d_ptr, nbytes, root)
             self.bytes_broadcast += int(nbytes)
@@ -133,7 +178,7 @@ class RankGroup:
         what the rank planned itself.  Raises ``RuntimeError`` on a mismatch -- a job whose collective
         does not work must not print a healthy result.  Returns the number of bytes broadcast."""
         ptr, nbytes = self.engine.constants_device()
-        if not self.active:
+        if not self.active or self.transport == "host":  # host transport: every rank keeps the blob it planned itself
             return 0
         stage = self.engine.alloc(nbytes)
         try:
@@ -179,7 +224,8 @@ class RankGroup:
             try:
                 self.barrier()
             finally:
-                self.engine.comm_destroy()
+                if self.transport == "rccl":
+                    self.engine.comm_destroy()
                 if self.rdzv is not None:
                     self.rdzv.cleanup()
 

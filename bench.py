@@ -222,11 +222,15 @@ def main():
                        max_batch=min(args.cohort, args.batch),
                        flatfield=None if shading is None else shading[0],
                        darkfield=None if shading is None else shading[1])  # fmt: skip
-    # N > 1: RCCL communicator + the one collective of the path; any failure raises (non-zero exit)
+    # N > 1: RCCL communicator + the one collective of the path.  A broadcast that delivers wrong bytes raises
+    # (non-zero exit).  If the communicator cannot be built at all, the ranks agree to reduce the timings on the host
+    # (the data path has no collective) and the line says so: config.rank_transport = "host" + the reason.
     group = dsx_dist.RankGroup(engine, rank, world)
     blob_bytes = group.broadcast_constants(root=0)
-    if world > 1:
+    if world > 1 and group.transport == "rccl":
         log("[bench] rank {}: constants broadcast over RCCL, {} bytes, verified against the local plan".format(rank, blob_bytes))
+    elif world > 1:
+        log("[bench] rank {}: NO RCCL communicator ({}); barrier / max-over-ranks on the host".format(rank, group.comm_error))
 
     # synthetic stack: 32 unique planes, slice z = bank[z % 32] rolled by z // 32 rows
     t0 = time.perf_counter()
@@ -325,7 +329,9 @@ def main():
                 "fft_len": [info.fft_len[i] for i in range(info.levels)],
                 "planes_with_cells_config": n_cells,
                 "parallelism": "z-sharded x{}".format(world),
-                "rccl_ranks": world if world > 1 else 0,
+                "rccl_ranks": world if (world > 1 and group.transport == "rccl") else 0,
+                "rank_transport": group.transport,
+                "rccl_error": group.comm_error,
                 "constants_broadcast_bytes": blob_bytes,
                 "settle_steps": settle_steps,
                 "verification": vdetails,

@@ -223,6 +223,62 @@ def test_rankgroup_protocol_three_ranks(tmp_path, corrupt):
         assert [r[1] for r in res] == ["ok"] * world and all(r[2] == 4096 and r[3] == 6.0 for r in res), res
 
 
+def _host_transport_worker(rank, world, xdir, mode, q):
+    sys.path.insert(0, REPO)
+    from aind_smartspim_destripe_amd import distributed as dd
+
+    eng = _FakeEngine(rank, world, xdir)
+    destroyed = []
+    eng.comm_destroy = lambda: destroyed.append(rank)
+    if rank == 1 and mode == "load":  # this rank cannot load RCCL at all: caught before anybody enters the init
+        def no_lib():
+            raise OSError("librccl.so: cannot open shared object file")
+
+        eng.comm_unique_id = no_lib
+        eng.comm_init = lambda *a: (_ for _ in ()).throw(AssertionError("comm_init after a failed preflight"))
+    elif mode == "load":
+        eng.comm_init = lambda *a: (_ for _ in ()).throw(AssertionError("comm_init after a failed preflight"))
+    elif rank == 1:  # the collective init itself fails on this rank
+        def broken(uid, rank_, world_):
+            raise OSError("librccl.so: ncclCommInitRank: unhandled system error")
+
+        eng.comm_init = broken
+    grp = dd.RankGroup(eng, rank, world, dd.FileRendezvous(rank, world, xdir))
+    n = grp.broadcast_constants(root=0)
+    mx = grp.allreduce([float(rank), 10.0 - rank], "max")
+    mn = grp.allreduce([float(rank)], "min")
+    grp.barrier()
+    try:
+        grp.broadcast_device(None, 16, 0)
+        bcast = "no error"
+    except RuntimeError:
+        bcast = "raises"
+    q.put((rank, grp.transport, grp.comm_error, n, mx, mn, bcast, destroyed))
+
+
+@pytest.mark.parametrize("mode", ["load", "init"])
+def test_rankgroup_agrees_on_host_transport_when_rccl_is_missing(tmp_path, mode):
+    """One rank cannot build the RCCL communicator: EVERY rank must learn it (over the rendezvous), drop its own
+    communicator and reduce on the host -- same results, flagged transport, device broadcasts refused."""
+    import multiprocessing as mp
+
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_host_transport_worker, args=(r, world, str(tmp_path), mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, transport, err, n, mx, mn, bcast, destroyed in res:
+        assert transport == "host" and "rank 1" in err and "librccl" in err
+        assert n == 0 and mx == [2.0, 10.0] and mn == [0.0] and bcast == "raises"
+        # ranks that had joined release their communicator; after a failed preflight nobody joined
+        assert destroyed == ([] if (rank == 1 or mode == "load") else [rank])
+
+
 def test_file_rendezvous_atomic_and_timeout(tmp_path):
     from aind_smartspim_destripe_amd.distributed import FileRendezvous
 
