@@ -27,7 +27,29 @@ DSX_HD dsx_c32 dsx_add(dsx_c32 a, dsx_c32 b) { return a + b; }
 DSX_HD dsx_c32 dsx_sub(dsx_c32 a, dsx_c32 b) { return a - b; }
 // a * (-i)
 DSX_HD dsx_c32 dsx_mul_mi(dsx_c32 a) { return dsx_c32{a.y, -a.x}; }
-DSX_HD dsx_c32 dsx_mul(dsx_c32 a, dsx_c32 b) { return a.xx * b + a.yy * dsx_c32{-b.y, b.x}; }
+// (a - b) * (-i) = (a.y - b.y, b.x - a.x) in one packed add (half selection and signs on the operands)
+DSX_HD dsx_c32 dsx_sub_mi(dsx_c32 a, dsx_c32 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DSX_NO_ASM_CMUL)
+  dsx_c32 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+#else
+  return dsx_c32{a.y - b.y, b.x - a.x};
+#endif
+}
+// complex product in two packed instructions: the half selection (op_sel) and the sign (neg_lo) ride on the
+// operands, where the compiler builds {-b.y, b.x} with a v_xor and a v_mov first
+//   t = (-a.y b.y, a.y b.x);   d = (a.x b.x + t.lo, a.x b.y + t.hi)
+DSX_HD dsx_c32 dsx_mul(dsx_c32 a, dsx_c32 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DSX_NO_ASM_CMUL)
+  dsx_c32 t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
+  return d;
+#else
+  return a.xx * b + a.yy * dsx_c32{-b.y, b.x};
+#endif
+}
 DSX_HD dsx_c32 dsx_scale(dsx_c32 a, float s) { return a * s; }
 // a * s + b
 DSX_HD dsx_c32 dsx_fma_s(dsx_c32 a, float s, dsx_c32 b) { return a * s + b; }
@@ -49,6 +71,7 @@ DSX_HD dsx_c32 dsx_mul(dsx_c32 a, dsx_c32 b) {
 }
 // a * (-i)
 DSX_HD dsx_c32 dsx_mul_mi(dsx_c32 a) { return dsx_mk(a.y, -a.x); }
+DSX_HD dsx_c32 dsx_sub_mi(dsx_c32 a, dsx_c32 b) { return dsx_mk(a.y - b.y, b.x - a.x); }
 DSX_HD dsx_c32 dsx_scale(dsx_c32 a, float s) { return dsx_mk(a.x * s, a.y * s); }
 // a * s + b
 DSX_HD dsx_c32 dsx_fma_s(dsx_c32 a, float s, dsx_c32 b) { return dsx_mk(a.x * s + b.x, a.y * s + b.y); }
@@ -97,12 +120,11 @@ struct dsx_bfly<3> {
   DSX_HD static void run(dsx_c32* v) {
     const float S = 0.86602540378443864676f;  // sin(2 pi / 3)
     dsx_c32 t = dsx_add(v[1], v[2]);
-    dsx_c32 d = dsx_sub(v[1], v[2]);
+    dsx_c32 dm = dsx_sub_mi(v[1], v[2]);  // -i (x1 - x2)
     dsx_c32 u = dsx_fma_s(t, -0.5f, v[0]);
-    dsx_c32 w = dsx_scale(dsx_mul_mi(d), S);  // -i sin(2pi/3) (x1 - x2)
     v[0] = dsx_add(v[0], t);
-    v[1] = dsx_add(u, w);
-    v[2] = dsx_sub(u, w);
+    v[1] = dsx_fma_s(dm, S, u);   // u - i sin(2pi/3) (x1 - x2)
+    v[2] = dsx_fma_s(dm, -S, u);
   }
 };
 
@@ -112,7 +134,7 @@ struct dsx_bfly<4> {
     dsx_c32 t0 = dsx_add(v[0], v[2]);
     dsx_c32 t1 = dsx_sub(v[0], v[2]);
     dsx_c32 t2 = dsx_add(v[1], v[3]);
-    dsx_c32 t3 = dsx_mul_mi(dsx_sub(v[1], v[3]));
+    dsx_c32 t3 = dsx_sub_mi(v[1], v[3]);
     v[0] = dsx_add(t0, t2);
     v[1] = dsx_add(t1, t3);
     v[2] = dsx_sub(t0, t2);
@@ -277,7 +299,7 @@ DSX_HD void dsx_bfly_odd(dsx_c32* v) {
 #endif
   for (int j = 1; j <= HP; ++j) {
     sp[j - 1] = dsx_add(v[j], v[P - j]);
-    sm[j - 1] = dsx_mul_mi(dsx_sub(v[j], v[P - j]));  // -i (x_j - x_{P-j})
+    sm[j - 1] = dsx_sub_mi(v[j], v[P - j]);  // -i (x_j - x_{P-j})
   }
   const dsx_c32 x0 = v[0];
   dsx_c32 dc = x0;
@@ -427,7 +449,7 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
     for (int j = 1; j <= JK; ++j) {
       const dsx_c32 x = v[j], y = v[R - j];
       v[j] = dsx_add(x, y);
-      v[R - j] = dsx_mul_mi(dsx_sub(x, y));  // -i (x_j - x_{R-j})
+      v[R - j] = dsx_sub_mi(x, y);  // -i (x_j - x_{R-j})
     }
     const dsx_c32 x0 = v[0];
     dsx_c32 dc = x0;
