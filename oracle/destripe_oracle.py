@@ -225,8 +225,8 @@ def histogram256(q, nbins=256):
     return counts, edges
 
 
-def otsu_from_histogram(counts, edges):
-    """Class-variance arg-max of skimage ``threshold_otsu`` given the 256-bin histogram."""
+def otsu_variance_curve(counts, edges):
+    """(bin centres, between-class variance per split) of skimage ``threshold_otsu`` given the 256-bin histogram."""
     counts = counts.astype(float)
     bin_centers = (edges[:-1] + edges[1:]) / 2.0
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -235,6 +235,12 @@ def otsu_from_histogram(counts, edges):
         mean1 = np.cumsum(counts * bin_centers) / weight1
         mean2 = (np.cumsum((counts * bin_centers)[::-1]) / weight2[::-1])[::-1]
         variance12 = weight1[:-1] * weight2[1:] * (mean1[:-1] - mean2[1:]) ** 2
+    return bin_centers, variance12
+
+
+def otsu_from_histogram(counts, edges):
+    """Class-variance arg-max of skimage ``threshold_otsu`` given the 256-bin histogram."""
+    bin_centers, variance12 = otsu_variance_curve(counts, edges)
     idx = int(np.argmax(variance12))
     return bin_centers[idx]
 
@@ -320,16 +326,18 @@ def gaussian_filter(shape, sigma):
     return np.broadcast_to(g, shape).copy()
 
 
-def filter_level(ch, sigma_rows, max_threshold, stages=None, mask_override=None):
+def filter_level(ch, sigma_rows, max_threshold, stages=None, mask_override=None, otsu_override=None):
     """Body of the per-level loop, ``filtering.py:187-217``; returns ``ch_filtered`` (float64).
 
     ``sigma_rows`` is ``s = ch.shape[0] * width_fraction`` (``filtering.py:213``).
     ``mask_override`` (tests only): take the hard decisions ``|ch| > threshold`` from the caller instead
     -- the parity tests use it to show that, GIVEN the same decisions, the engine agrees everywhere.
+    ``otsu_override`` (tests only): take the Otsu value from the caller -- used when the class-variance curve has
+    two (near-)equal maxima and the engine sits on the other one (tests/parity_util.py, "Otsu ties").
     """
     ch_sq = ch**2
     ch_power = np.sqrt(ch_sq)
-    otsu = threshold_otsu(ch_sq)
+    otsu = threshold_otsu(ch_sq) if otsu_override is None else ch_sq.dtype.type(otsu_override)
     otsu_threshold_sqrt = np.sqrt(otsu)
     threshold = min(max_threshold, otsu_threshold_sqrt)
     mask = ch_power > threshold
@@ -358,12 +366,13 @@ def filter_level(ch, sigma_rows, max_threshold, stages=None, mask_override=None)
 
 
 def log_space_fft_filtering(
-    input_image, wavelet="db3", level=0, sigma=64, max_threshold=4, return_stages=False, mask_overrides=None
+    input_image, wavelet="db3", level=0, sigma=64, max_threshold=4, return_stages=False, mask_overrides=None,
+    otsu_overrides=None
 ):
     """``filtering.py:139-224`` for a 2-D plane.
 
     Stage list (``return_stages=True``) is ordered coarse -> fine like the reference loop;
-    ``mask_overrides`` (tests only, same order): see :func:`filter_level`.
+    ``mask_overrides`` / ``otsu_overrides`` (tests only, same order, entries may be None): see :func:`filter_level`.
     """
     if wavelet != "db3":
         raise ValueError("the oracle restates db3 only (production wavelet, run_capsule.py:374-390)")
@@ -381,7 +390,8 @@ def log_space_fft_filtering(
     for i, (ch, cv, cd) in enumerate(detail):
         s = ch.shape[0] * width_fraction
         ch_filtered = filter_level(ch, s, max_threshold, stages,
-                                   None if mask_overrides is None else mask_overrides[i])
+                                   None if mask_overrides is None else mask_overrides[i],
+                                   None if otsu_overrides is None else otsu_overrides[i])
         coeff_filtered.append((ch_filtered, cv, cd))
     img_log_filtered = waverec2(coeff_filtered)
     img_filtered = np.exp(img_log_filtered) + 1.0

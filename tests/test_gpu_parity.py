@@ -551,3 +551,29 @@ def test_fused_kernel_edge_shapes(engine, shape):
             assert np.abs(ch - st["ch"]).max() <= 2e-5 * scale * (2**lv), (shape, lv)
     finally:
         engine.set_stop_after(0)
+
+
+def test_otsu_tie_plane(engine, capsys):
+    """A plane whose level-2 class-variance curve has two maxima that agree to 1.5e-7 relative (found by
+    tools/fuzz_parity.py): the reference's arg-max lands on bin 50, the engine's -- its float32 coefficients differ
+    by 1e-6 -- on bin 51, one bin width (1 %) higher.  The parity statement (tests/parity_util.py, obligations (d) and
+    (e)) must recognise the tie from the ORACLE's own curve, take the engine's bin in the oracle and hold everywhere
+    else; a wrong bin without a tie must still fail."""
+    import parity_util
+
+    h, w = 244, 971
+    planes = np.stack([synth.synthetic_plane(k, h, w) for k in (921, 971)])
+    deltas = gpu_deltas(engine, planes)
+    out = filtering.destripe_planes(planes, "X_0_Y_0", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
+                                    synth.ZARR_PATH_HIGH_INT, out_dtype=np.float32, max_batch=2)
+    for k in range(2):
+        _check_plane(out[k], planes[k], deltas[k], ((h, w), k))
+    assert "Otsu tie at level index [1]" in capsys.readouterr().out
+    # the tie test is not a loophole: an Otsu value two bins away from the maximum is rejected
+    _, _, _, _, stages = oracle_plane(planes[1])
+    bad = list(deltas[1].otsu)
+    q = stages[1]["ch"] ** 2
+    centres, var = orc.otsu_variance_curve(*orc.histogram256(q))
+    bad[1] = float(centres[int(np.argmax(var)) + 3])
+    with pytest.raises(AssertionError):
+        parity_util.find_otsu_ties(bad, stages)
