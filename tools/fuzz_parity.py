@@ -25,11 +25,17 @@ for c in range(cases):
     h = int(rng.integers(40, 700))
     n = int(rng.integers(1, 5))
     as_f32 = rng.random() < 0.3
+    # random filter parameters: decomposition depth, low-pass width, threshold cap, fg/bg decision level
+    cells = {"wavelet": "db3", "level": [None, None, 1, 2, 3, 5][int(rng.integers(0, 6))],
+             "sigma": float(rng.choice([16, 64, 100, 250])), "max_threshold": float(rng.choice([0.5, 3, 12]))}
+    nocells = {"wavelet": "db3", "level": [None, None, 1, 2, 4][int(rng.integers(0, 5))],
+               "sigma": float(rng.choice([32, 128, 512])), "max_threshold": float(rng.choice([1, 12, 100]))}
+    high_int = int(rng.choice([100, 160, 2500]))
     planes = np.stack([synth.synthetic_plane(int(rng.integers(0, 1000)), h, w) for _ in range(n)])
     src = planes.astype(np.float32) if as_f32 else planes
-    deltas = gpu_deltas(eng, src)
-    out, cfg = filtering.destripe_planes(src, "X_0_Y_0", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
-                                         synth.ZARR_PATH_HIGH_INT, out_dtype=np.float32, return_config=True, max_batch=n)
+    deltas = gpu_deltas(eng, src, high_int=high_int, cells=cells, nocells=nocells)
+    out, cfg = filtering.destripe_planes(src, "X_0_Y_0", nocells, cells, None,
+                                         high_int, out_dtype=np.float32, return_config=True, max_batch=n)
     for k in range(n):
         # The engine computes in float32 like the reference's Zarr path (float32 planes, zarr_destriper.py:1049); for
         # uint16 input the reference's TIFF path runs in float64 and can pick the neighbouring Otsu bin on a plateau
@@ -38,9 +44,9 @@ for c in range(cases):
         err = None
         for regime in ((np.float32,) if as_f32 else (np.uint16, np.float32)):
             img = src[k].astype(regime)
-            which, _, _, ref, stages = oracle_plane(img)
+            which, _, _, ref, stages = oracle_plane(img, high_int=high_int, cells=cells, nocells=nocells)
             assert int(cfg[k]) == which, (h, w, k)
-            cfgd = synth.CELLS_CONFIG if which else synth.NO_CELLS_CONFIG
+            cfgd = cells if which else nocells
             try:
                 check_plane(out[k], img, deltas[k], ((h, w), np.dtype(regime).name, k), cfgd, max_flips, ref=ref, stages=stages)
                 err = None
@@ -51,8 +57,7 @@ for c in range(cases):
         if err is not None:
             raise err
     # uint16 result path (truncation): within one count of the float result
-    out16 = filtering.destripe_planes(src, "X_0_Y_0", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None,
-                                      synth.ZARR_PATH_HIGH_INT, out_dtype=np.uint16, max_batch=n)
+    out16 = filtering.destripe_planes(src, "X_0_Y_0", nocells, cells, None, high_int, out_dtype=np.uint16, max_batch=n)
     d = np.abs(out16.astype(np.float64) - np.clip(np.floor(out.astype(np.float64)), 0, 65535))
     assert d.max() <= 1.0, ((h, w), float(d.max()))
     worst = max(worst, float(d.max()))
