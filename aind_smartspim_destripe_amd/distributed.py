@@ -223,6 +223,14 @@ class RankGroup:
         if self.active:
             try:
                 self.barrier()
+                # rank 0 removes the rendezvous directory: only once every other rank has said it is done reading
+                # (with the host transport the barrier itself lives in those files)
+                if self.rdzv is not None:
+                    if self.rank != 0:
+                        self.rdzv.put("bye.{}".format(self.rank), b"1")
+                    else:
+                        for r in range(1, self.world):
+                            self.rdzv.get("bye.{}".format(r))
             finally:
                 if self.transport == "rccl":
                     self.engine.comm_destroy()

@@ -207,6 +207,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # DSX_SHARE_GPU=1 (rehearsal of the multi-rank launch on a box with fewer GPUs than ranks): ranks share the
+    # devices round robin.  RCCL refuses two ranks on one GPU, so such a run also exercises the agreed host transport.
+    shared_gpu = False
+    if os.environ.get("DSX_SHARE_GPU") == "1":
+        ndev = int(eng_mod.load_library().dsx_device_count())
+        if ndev > 0:
+            local, shared_gpu = local % ndev, world > ndev
     if world != args.gpus:
         log("[bench] WORLD_SIZE {} != --gpus {}; using WORLD_SIZE".format(world, args.gpus))
 
@@ -331,6 +338,7 @@ def main():
                 "parallelism": "z-sharded x{}".format(world),
                 "rccl_ranks": world if (world > 1 and group.transport == "rccl") else 0,
                 "rank_transport": group.transport,
+                "ranks_share_gpus": shared_gpu,
                 "rccl_error": group.comm_error,
                 "constants_broadcast_bytes": blob_bytes,
                 "settle_steps": settle_steps,

@@ -253,7 +253,12 @@ def _host_transport_worker(rank, world, xdir, mode, q):
         bcast = "no error"
     except RuntimeError:
         bcast = "raises"
-    q.put((rank, grp.transport, grp.comm_error, n, mx, mn, bcast, destroyed))
+    import time
+
+    if rank == 2:
+        time.sleep(0.3)  # a late reader: rank 0 must not remove the rendezvous files under it
+    grp.close()
+    q.put((rank, grp.transport, grp.comm_error, n, mx, mn, bcast, list(destroyed)))
 
 
 @pytest.mark.parametrize("mode", ["load", "init"])
