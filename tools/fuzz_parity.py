@@ -12,53 +12,66 @@ from aind_smartspim_destripe_amd import engine as eng_mod, filtering, synth
 from oracle import destripe_oracle as orc
 from parity_util import check_plane, gpu_deltas, oracle_plane
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
-max_flips = lambda size: max(3, int(2e-5 * size))
-eng = eng_mod.DestripeEngine(0)
-t0 = time.time(); worst = 0.0; n_regime_retries = 0
-for c in range(cases):
-    anchor = int(rng.choice([64, 122, 128, 244, 256, 488, 512, 732, 976, 1220, 1708, 2048]))
-    w = max(40, anchor + int(rng.integers(-9, 10)))
-    if rng.random() < 0.6: w = (w + 3) & ~3          # fused kernels need a multiple of 4
-    if rng.random() < 0.3: w = (w + 7) & ~7          # lane-pair I/O of the final kernel: multiple of 8
-    h = int(rng.integers(40, 700))
-    n = int(rng.integers(1, 5))
-    as_f32 = rng.random() < 0.3
-    # random filter parameters: decomposition depth, low-pass width, threshold cap, fg/bg decision level
-    cells = {"wavelet": "db3", "level": [None, None, 1, 2, 3, 5][int(rng.integers(0, 6))],
-             "sigma": float(rng.choice([16, 64, 100, 250])), "max_threshold": float(rng.choice([0.5, 3, 12]))}
-    nocells = {"wavelet": "db3", "level": [None, None, 1, 2, 4][int(rng.integers(0, 5))],
-               "sigma": float(rng.choice([32, 128, 512])), "max_threshold": float(rng.choice([1, 12, 100]))}
-    high_int = int(rng.choice([100, 160, 2500]))
-    planes = np.stack([synth.synthetic_plane(int(rng.integers(0, 1000)), h, w) for _ in range(n)])
-    src = planes.astype(np.float32) if as_f32 else planes
-    deltas = gpu_deltas(eng, src, high_int=high_int, cells=cells, nocells=nocells)
-    out, cfg = filtering.destripe_planes(src, "X_0_Y_0", nocells, cells, None,
-                                         high_int, out_dtype=np.float32, return_config=True, max_batch=n)
-    for k in range(n):
-        # The engine computes in float32 like the reference's Zarr path (float32 planes, zarr_destriper.py:1049); for
-        # uint16 input the reference's TIFF path runs in float64 and can pick the neighbouring Otsu bin on a plateau
-        # of the class-variance curve -- the two regimes of the reference differ from each other there, so a plane must
-        # satisfy the statement against ONE of them (the float64 regime is tried first).
-        err = None
-        for regime in ((np.float32,) if as_f32 else (np.uint16, np.float32)):
-            img = src[k].astype(regime)
-            which, _, _, ref, stages = oracle_plane(img, high_int=high_int, cells=cells, nocells=nocells)
-            assert int(cfg[k]) == which, (h, w, k)
-            cfgd = cells if which else nocells
-            try:
-                check_plane(out[k], img, deltas[k], ((h, w), np.dtype(regime).name, k), cfgd, max_flips, ref=ref, stages=stages)
-                err = None
-                break
-            except AssertionError as e:
-                err = e
-                n_regime_retries += 1
-        if err is not None:
-            raise err
-    # uint16 result path (truncation): within one count of the float result
-    out16 = filtering.destripe_planes(src, "X_0_Y_0", nocells, cells, None, high_int, out_dtype=np.uint16, max_batch=n)
-    d = np.abs(out16.astype(np.float64) - np.clip(np.floor(out.astype(np.float64)), 0, 65535))
-    assert d.max() <= 1.0, ((h, w), float(d.max()))
-    worst = max(worst, float(d.max()))
-print("fuzz: %d cases passed in %.0f s (uint16 vs floor(float32) result: max difference %.0f count; %d planes matched the float32 regime of the reference only)" % (cases, time.time() - t0, worst, n_regime_retries))
+
+
+def run(cases=40, seed=2026, eng=None):
+    """``cases`` random cases; raises AssertionError on the first plane that violates the parity statement.
+    Returns (planes checked, planes that needed the float32 regime of the reference)."""
+    rng = np.random.default_rng(seed)
+    own = eng is None
+    max_flips = lambda size: max(3, int(2e-5 * size))
+    eng = eng_mod.DestripeEngine(0) if own else eng
+    t0 = time.time(); worst = 0.0; n_regime_retries = 0; n_planes = 0
+    for c in range(cases):
+        anchor = int(rng.choice([64, 122, 128, 244, 256, 488, 512, 732, 976, 1220, 1708, 2048]))
+        w = max(40, anchor + int(rng.integers(-9, 10)))
+        if rng.random() < 0.6: w = (w + 3) & ~3          # fused kernels need a multiple of 4
+        if rng.random() < 0.3: w = (w + 7) & ~7          # lane-pair I/O of the final kernel: multiple of 8
+        h = int(rng.integers(40, 700))
+        n = int(rng.integers(1, 5))
+        as_f32 = rng.random() < 0.3
+        # random filter parameters: decomposition depth, low-pass width, threshold cap, fg/bg decision level
+        cells = {"wavelet": "db3", "level": [None, None, 1, 2, 3, 5][int(rng.integers(0, 6))],
+                 "sigma": float(rng.choice([16, 64, 100, 250])), "max_threshold": float(rng.choice([0.5, 3, 12]))}
+        nocells = {"wavelet": "db3", "level": [None, None, 1, 2, 4][int(rng.integers(0, 5))],
+                   "sigma": float(rng.choice([32, 128, 512])), "max_threshold": float(rng.choice([1, 12, 100]))}
+        high_int = int(rng.choice([100, 160, 2500]))
+        planes = np.stack([synth.synthetic_plane(int(rng.integers(0, 1000)), h, w) for _ in range(n)])
+        src = planes.astype(np.float32) if as_f32 else planes
+        deltas = gpu_deltas(eng, src, high_int=high_int, cells=cells, nocells=nocells)
+        out, cfg = filtering.destripe_planes(src, "X_0_Y_0", nocells, cells, None,
+                                             high_int, out_dtype=np.float32, return_config=True, max_batch=n)
+        for k in range(n):
+            # The engine computes in float32 like the reference's Zarr path (float32 planes, zarr_destriper.py:1049); for
+            # uint16 input the reference's TIFF path runs in float64 and can pick the neighbouring Otsu bin on a plateau
+            # of the class-variance curve -- the two regimes of the reference differ from each other there, so a plane must
+            # satisfy the statement against ONE of them (the float64 regime is tried first).
+            err = None
+            for regime in ((np.float32,) if as_f32 else (np.uint16, np.float32)):
+                img = src[k].astype(regime)
+                which, _, _, ref, stages = oracle_plane(img, high_int=high_int, cells=cells, nocells=nocells)
+                assert int(cfg[k]) == which, (h, w, k)
+                cfgd = cells if which else nocells
+                try:
+                    check_plane(out[k], img, deltas[k], ((h, w), np.dtype(regime).name, k), cfgd, max_flips, ref=ref, stages=stages)
+                    err = None
+                    break
+                except AssertionError as e:
+                    err = e
+                    n_regime_retries += 1
+            if err is not None:
+                raise err
+            n_planes += 1
+        # uint16 result path (truncation): within one count of the float result
+        out16 = filtering.destripe_planes(src, "X_0_Y_0", nocells, cells, None, high_int, out_dtype=np.uint16, max_batch=n)
+        d = np.abs(out16.astype(np.float64) - np.clip(np.floor(out.astype(np.float64)), 0, 65535))
+        assert d.max() <= 1.0, ((h, w), float(d.max()))
+        worst = max(worst, float(d.max()))
+    print("fuzz: %d cases passed in %.0f s (uint16 vs floor(float32) result: max difference %.0f count; %d planes matched the float32 regime of the reference only)" % (cases, time.time() - t0, worst, n_regime_retries))
+    if own:
+        eng.close()
+    return n_planes, n_regime_retries
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
