@@ -21,7 +21,7 @@ def run(cases=40, seed=2026, eng=None):
     own = eng is None
     max_flips = lambda size: max(3, int(2e-5 * size))
     eng = eng_mod.DestripeEngine(0) if own else eng
-    t0 = time.time(); worst = 0.0; n_regime_retries = 0; n_planes = 0
+    t0 = time.time(); worst = 0.0; n_regime_retries = 0; n_planes = 0; n_batched = 0
     for c in range(cases):
         anchor = int(rng.choice([64, 122, 128, 244, 256, 488, 512, 732, 976, 1220, 1708, 2048]))
         w = max(40, anchor + int(rng.integers(-9, 10)))
@@ -62,12 +62,23 @@ def run(cases=40, seed=2026, eng=None):
             if err is not None:
                 raise err
             n_planes += 1
+        # now and then: the same planes many times over, split into cohorts and sub-cohort streams -- every copy of a
+        # plane must come out bit-identical to the small run above, wherever it sits in the batch
+        if rng.random() < 0.12 and h * w <= 300 * 600:
+            reps = int(rng.integers(33, 80))
+            idx = rng.integers(0, n, size=reps)
+            big = src[idx]
+            mb = int(rng.choice([16, 32, 48, reps]))
+            out_big = filtering.destripe_planes(big, "X_0_Y_0", nocells, cells, None, high_int, out_dtype=np.float32,
+                                                max_batch=mb)
+            assert np.array_equal(out_big, out[idx]), ("batch position dependence", (h, w), reps, mb)
+            n_batched += 1
         # uint16 result path (truncation): within one count of the float result
         out16 = filtering.destripe_planes(src, "X_0_Y_0", nocells, cells, None, high_int, out_dtype=np.uint16, max_batch=n)
         d = np.abs(out16.astype(np.float64) - np.clip(np.floor(out.astype(np.float64)), 0, 65535))
         assert d.max() <= 1.0, ((h, w), float(d.max()))
         worst = max(worst, float(d.max()))
-    print("fuzz: %d cases passed in %.0f s (uint16 vs floor(float32) result: max difference %.0f count; %d planes matched the float32 regime of the reference only)" % (cases, time.time() - t0, worst, n_regime_retries))
+    print("fuzz: %d cases passed in %.0f s (uint16 vs floor(float32) result: max difference %.0f count; %d planes matched the float32 regime of the reference only; %d big-batch bit-identity checks)" % (cases, time.time() - t0, worst, n_regime_retries, n_batched))
     if own:
         eng.close()
     return n_planes, n_regime_retries
