@@ -40,6 +40,11 @@ one level up, with its own proof obligations:
 (e) the oracle is then re-run with that bin chosen at that level (``otsu_overrides``), and (a)-(c) must hold against
     that run: given the same choice among tied maxima, everything else agrees as before.  Ties are counted and
     printed.
+
+Levels without information.  A level whose coefficients all lie below the float32 round-off of the analysis (a constant
+plane: cH == 0 in exact arithmetic) has noise for an Otsu value and for masks on either side; it is left out of (a) and
+(d) and stays under the pixel comparison (``numerically_empty``).  Likewise a coefficient whose unmasked Delta is exactly
+0 in the oracle cannot be read back as masked / unmasked and is not counted (``tools/fuzz_patterns.py``).
 """
 
 import numpy as np
@@ -51,6 +56,14 @@ from oracle import destripe_oracle as orc
 REL_TOL = 1e-4        # north star tolerance
 NEAR_THRESHOLD = 1e-3  # a flipped coefficient must be this close (relative) to the threshold
 OTSU_TIE = 1e-5        # two bins count as tied maxima of the class-variance curve within this (relative)
+
+
+def numerically_empty(st, lv):
+    """A level whose coefficients are ALL below the float32 round-off of the analysis (2e-5 * 2^level, the bound the
+    stage tests hold the engine's cH to): a constant plane has cH == 0 in exact arithmetic, and what either side
+    computes instead is noise -- its Otsu value and masks decide nothing (every Delta is below the same bound).  Such a
+    level is left out of the decision accounting (a), (d); the pixel comparison (b), (c) still covers it."""
+    return float(np.abs(st["ch"]).max()) <= 2e-5 * (2 ** lv)
 
 
 def rel_err(a, b):
@@ -104,7 +117,7 @@ def find_otsu_ties(otsu_gpu, stages, ch_gpu=None):
     overrides, any_tie = [], False
     for lv, (og, st) in enumerate(zip(otsu_gpu, stages)):
         oref = st["otsu"]
-        if abs(og - oref) <= 1e-4 * max(abs(oref), 1e-30):
+        if abs(og - oref) <= 1e-4 * max(abs(oref), 1e-30) or numerically_empty(st, lv):
             overrides.append(None)
             continue
         q = st["ch"] ** 2
@@ -142,9 +155,14 @@ def find_flips(deltas, stages, out_h):
     for lv, (delta, st) in enumerate(zip(deltas, stages)):
         thr = st["threshold"]
         mask_ref = np.abs(st["ch"]) > thr
-        mask_gpu = delta == 0.0  # an unmasked coefficient has Delta == 0 only by coincidence
+        mask_gpu = delta == 0.0  # an unmasked coefficient has Delta == 0 only by coincidence ...
+        # ... or by construction: where the oracle's own unmasked Delta is exactly 0 (constant levels: a plane of one
+        # value has cH == 0 and threshold 0 everywhere) the read-back cannot tell the two apart and says nothing
+        readable = mask_ref | ((np.asarray(st["ch_filtered"]) - st["ch"]) != 0)
         near = np.abs(np.abs(st["ch"]) - thr) <= NEAR_THRESHOLD * thr
-        flip = (mask_gpu != mask_ref) & near
+        flip = (mask_gpu != mask_ref) & near & readable
+        if numerically_empty(st, lv):
+            flip[:] = False
         counts.append(int(flip.sum()))
         forced.append(np.where(flip, mask_gpu, mask_ref))
         s = 1 << (lv + 1)

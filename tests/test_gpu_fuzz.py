@@ -21,3 +21,12 @@ def test_fuzz_parity_30_cases():
         warnings.simplefilter("ignore")  # "level too high" for tiny planes, as pywt warns in the reference
         planes, _ = fuzz_parity.run(cases=30, seed=99)
     assert planes >= 30
+
+
+def test_degenerate_planes():
+    """All-zero, saturated, two-valued, one hot pixel, constant rows / columns, checkerboard, ramp, 0..3-count noise,
+    a block on zero background (tools/fuzz_patterns.py) at three shapes: constant coefficient levels (Otsu's early-out,
+    thresholds of 0, levels that are pure round-off noise) against the oracle under the same statement."""
+    import fuzz_patterns
+
+    assert fuzz_patterns.run() == 36
