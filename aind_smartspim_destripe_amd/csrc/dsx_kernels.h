@@ -1945,8 +1945,21 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
       }
     }
     float r[4];
+    if (SHADE) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = final_px<SHADE>(a, c0[e], px[e], dk[e], fl[e]);  // all four: stores are masked
+      for (int e = 0; e < 4; ++e) r[e] = final_px<SHADE>(a, c0[e], px[e], dk[e], fl[e]);  // all four: stores are masked
+    } else {
+      // final_px for pixel pairs: (1 + x) and the multiply-add as packed FP32 (same roundings as the scalar form)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const dsx_f2 one = {1.0f, 1.0f};
+        const dsx_f2 x1 = dsx_f2{px[2 * h], px[2 * h + 1]} + one;
+        const dsx_f2 ex = {__builtin_amdgcn_exp2f(c0[2 * h]), __builtin_amdgcn_exp2f(c0[2 * h + 1])};
+        const dsx_f2 v = pk_fma(x1, ex, one);
+        r[2 * h] = v.x;
+        r[2 * h + 1] = v.y;
+      }
+    }
     if (pk_out != nullptr) {  // PAIR: hand the packed uint16 row back, the caller stores row pairs
       unsigned u[4];
 #pragma unroll
