@@ -364,10 +364,15 @@ __device__ __forceinline__ void march_consume(const Fwd1Args& a, const MarchRaw&
           if (px[e] >= a.fg_cutoff_u16) { st.isum_fg += px[e]; st.cnt++; }
       }
     }
-    x[0] = __builtin_amdgcn_logf(1.0f + (float)(u0 & 0xFFFFu));
-    x[1] = __builtin_amdgcn_logf(1.0f + (float)(u0 >> 16));
-    x[2] = __builtin_amdgcn_logf(1.0f + (float)(u1 & 0xFFFFu));
-    x[3] = __builtin_amdgcn_logf(1.0f + (float)(u1 >> 16));
+    // 1 + x as a packed add on the converted pairs (one v_cvt with a 16-bit source select per pixel + half a v_pk_add;
+    // written with scalar adds the compiler adds 1 in the integer domain first: two instructions per pixel)
+    const dsx_f2 one = {1.0f, 1.0f};
+    const dsx_f2 p01 = dsx_f2{(float)(u0 & 0xFFFFu), (float)(u0 >> 16)} + one;
+    const dsx_f2 p23 = dsx_f2{(float)(u1 & 0xFFFFu), (float)(u1 >> 16)} + one;
+    x[0] = __builtin_amdgcn_logf(p01.x);
+    x[1] = __builtin_amdgcn_logf(p01.y);
+    x[2] = __builtin_amdgcn_logf(p23.x);
+    x[3] = __builtin_amdgcn_logf(p23.y);
     return;
   }
   float v[4] = {r.f.x, r.f.y, r.f.z, r.f.w};
@@ -1687,6 +1692,15 @@ __device__ __forceinline__ unsigned swap_adjacent(unsigned v) {
   return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
 }
 
+// Two results as packed uint16: v_cvt_u32_f32 saturates below at 0 (negative, NaN) and v_cvt_pk_u16_u32 above at 65535 --
+// the clip of the reference's uint16 assignment without a compare per pixel.
+__device__ __forceinline__ unsigned pack_u16_sat(float lo, float hi) {
+  typedef unsigned short dsx_u16x2 __attribute__((ext_vector_type(2)));
+  union { dsx_u16x2 v; unsigned u; } c;
+  c.v = __builtin_amdgcn_cvt_pk_u16((unsigned)lo, (unsigned)hi);
+  return c.u;
+}
+
 // c0l = c0 * log2(e) (the factor is folded into the axis-0 synthesis taps of the last level)
 template <bool SHADE>
 __device__ __forceinline__ float final_px(const FinalArgs& a, float c0l, float x, float dark, float flat) {
@@ -1961,30 +1975,24 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
       }
     }
     if (pk_out != nullptr) {  // PAIR: hand the packed uint16 row back, the caller stores row pairs
-      unsigned u[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) u[e] = (unsigned)fminf(r[e], 65535.f);
-      (*pk_out)[0] = u[0] | (u[1] << 16);
-      (*pk_out)[1] = u[2] | (u[3] << 16);
+      (*pk_out)[0] = pack_u16_sat(r[0], r[1]);
+      (*pk_out)[1] = pack_u16_sat(r[2], r[3]);
       return;
     }
     const long long o = plane * a.out_plane_stride + (long long)gy * a.wout + x0;
     if (a.ablate & 32) {
       if (r[0] + r[1] + r[2] + r[3] == -12345.f) ((float*)a.out)[0] = 0.f;  // keeps the arithmetic alive
     } else if (a.out_dtype == 0) {
-      unsigned u[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) u[e] = (unsigned)fminf(r[e], 65535.f);  // float -> uint saturates below at 0
       if (vec_out) {
         dsx_u32x2 pk;
-        pk.x = u[0] | (u[1] << 16);
-        pk.y = u[2] | (u[3] << 16);
+        pk.x = pack_u16_sat(r[0], r[1]);
+        pk.y = pack_u16_sat(r[2], r[3]);
         // written once, not read again here
         __builtin_amdgcn_raw_buffer_store_b64(pk, rs_out, vo_out, (unsigned)(gy * a.wout) * 2u, kBufNT);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (x0 + e < a.wout) ((uint16_t*)a.out)[o + e] = (uint16_t)u[e];
+          if (x0 + e < a.wout) ((uint16_t*)a.out)[o + e] = (uint16_t)(unsigned)fminf(r[e], 65535.f);
       }
     } else {
       if (vec_out) {
