@@ -867,11 +867,12 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
   // position, so only values within 1e-3 of an integer need the comparison against the actual edges.
   const double first64 = (double)qmin, step64 = ((double)qmax - (double)qmin) / 256.0;
   auto edge = [&](int i) { return (float)__dadd_rn(__dmul_rn((double)i, step64), first64); };
+  const float off = -qmin * scale;
   auto bin_of = [&](float q) {
-    const float fi = (q - qmin) * scale;
+    const float fi = fmaf(q, scale, off);  // = (q - qmin) * scale to a few ulp of 256
     int idx = min((int)fi, 255);
-    const float fr = fi - (float)idx;
-    if (fr < 1e-3f || fr > 0.999f) {
+    const float fr = __builtin_amdgcn_fractf(fi);  // 0 for the clamped q == qmax: takes the exact path
+    if (fabsf(fr - 0.5f) > 0.499f) {
       const float e_lo = edge(idx);
       const float e_hi = (idx == 255) ? qmax : edge(idx + 1);
       if (q < e_lo) idx -= 1;
@@ -883,8 +884,8 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
   // the four lowest bins hold most of the mass: byte-packed per-lane counters, flushed before overflow
   unsigned packed = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, since_flush = 0;
   auto count = [&](int idx) {
-    if (idx < 4) packed += 1u << (8 * idx);
-    else atomicAdd(&s_h[idx], 1u);
+    packed += (idx < 4) ? (1u << (8 * idx)) : 0u;  // branch-free for the bins that hold the mass
+    if (idx >= 4) atomicAdd(&s_h[idx], 1u);
   };
   auto flush = [&]() {
     c0 += packed & 0xFFu; c1 += (packed >> 8) & 0xFFu; c2 += (packed >> 16) & 0xFFu; c3 += packed >> 24;
@@ -897,12 +898,19 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
   // The kernel waits on memory, not on arithmetic: two rows x two 256-column chunks = four independent
   // 16-byte loads are in flight per lane before the first value is binned (clamped addresses keep the
   // loads unconditional; what a clamped load returns is not counted).
-  auto tally = [&](const float4& v, int c, bool on) {
+  // full (wave-uniform): the 256-column chunk lies inside the row for every lane -- no per-element bounds tests
+  auto tally = [&](const float4& v, int c, bool on, bool full) {
     if (on) {
       count(bin_of(v.x * v.x));
-      if (c + 1 < a.w) count(bin_of(v.y * v.y));
-      if (c + 2 < a.w) count(bin_of(v.z * v.z));
-      if (c + 3 < a.w) count(bin_of(v.w * v.w));
+      if (full) {
+        count(bin_of(v.y * v.y));
+        count(bin_of(v.z * v.z));
+        count(bin_of(v.w * v.w));
+      } else {
+        if (c + 1 < a.w) count(bin_of(v.y * v.y));
+        if (c + 2 < a.w) count(bin_of(v.z * v.z));
+        if (c + 3 < a.w) count(bin_of(v.w * v.w));
+      }
       since_flush += 4;
     }
   };
@@ -923,10 +931,12 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
       const float4 va0 = *(const float4*)(rowa + c), va1 = *(const float4*)(rowa + c2l);
       const float4 vb0 = *(const float4*)(rowb + c), vb1 = *(const float4*)(rowb + c2l);
 #endif
-      tally(va0, c, true);
-      tally(va1, c2, on2);
-      tally(vb0, c, two);
-      tally(vb1, c2, two && on2);
+      const int cbase = c - 4 * lane;  // wave-uniform
+      const bool full0 = cbase + 256 <= a.w, full1 = cbase + 512 <= a.w;
+      tally(va0, c, true, full0);
+      tally(va1, c2, on2, full1);
+      tally(vb0, c, two, full0);
+      tally(vb1, c2, two && on2, full1);
       if (since_flush >= 236) flush();
     }
   }
