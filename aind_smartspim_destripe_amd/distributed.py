@@ -31,7 +31,7 @@ class FileRendezvous:
     sees a key either whole or not at all.
 
     The directory is keyed by the launcher's pid (``os.getppid()``: all ranks of a ``torchrun``
-    launch share it, consecutive launches do not) and ``MASTER_PORT``; ``DSX_RDZV_DIR`` overrides it
+    launch share it, consecutive launches do not), its start time and ``MASTER_PORT``; ``DSX_RDZV_DIR`` overrides it
     for launchers whose ranks do not share a parent.
     """
 
@@ -39,7 +39,13 @@ class FileRendezvous:
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         directory = directory or os.environ.get("DSX_RDZV_DIR")
         if directory is None:
-            tag = "{}_{}".format(os.getppid(), os.environ.get("MASTER_PORT", "0"))
+            ppid = os.getppid()
+            tag = "{}_{}".format(ppid, os.environ.get("MASTER_PORT", "0"))
+            try:  # the launcher's start time: a recycled pid (and a crashed run's left-over files) gets another directory
+                with open("/proc/{}/stat".format(ppid)) as f:
+                    tag += "_" + f.read().rsplit(")", 1)[1].split()[19]
+            except (OSError, IndexError):
+                pass
             directory = os.path.join(tempfile.gettempdir(), "dsx_rdzv_" + tag)
         self.dir = directory
         os.makedirs(self.dir, exist_ok=True)
