@@ -872,6 +872,18 @@ int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, i
     if (cfg_used)
       DSX_HIP(hipMemcpyAsync(cfg_used + start, d_cfg, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, use_main(ctx)));
     DSX_HIP(hipStreamSynchronize(use_main(ctx)));
+    // float32 planes: the forward kernel flags pixels whose log(1 + x) is not finite (PlaneStats::flags); with at
+    // least one decomposition level the reference raises ValueError for such a plane (numpy.histogram inside
+    // threshold_otsu: "autodetected range of [nan, nan] is not finite")
+    if (in_dtype == DSX_F32 && p.L > 0) {
+      std::vector<dsx::PlaneStats> hs((size_t)nb);
+      DSX_HIP(hipMemcpy(hs.data(), ctx->d_stats, sizeof(dsx::PlaneStats) * nb, hipMemcpyDeviceToHost));
+      for (int k = 0; k < nb; ++k)
+        if (hs[(size_t)k].flags & 1ull)
+          return fail(ctx, DSX_EVALUE, "plane " + std::to_string(start + k) +
+                                           ": autodetected range of [nan, nan] is not finite (a pixel is NaN, "
+                                           "infinite or <= -1)");
+    }
   }
   return DSX_OK;
 }

@@ -93,7 +93,9 @@ struct PlaneStats {
   double sum_fg;               // sum of pixels in the foreground class (>= cut-off)
   double sum_all;              // sum of all pixels
   unsigned long long cnt_fg;   // pixels in the foreground class
-  unsigned long long pad_;
+  // bit 0: a float32 pixel was NaN, infinite or <= -1 (log(1 + x) is not finite: the reference dies in
+  // numpy.histogram, filtering.py:188 -> skimage threshold_otsu); dsx_run_host turns it into DSX_EVALUE
+  unsigned long long flags;
 };
 
 // Half-sample symmetric extension index (np.pad 'symmetric'), any distance.
@@ -197,7 +199,9 @@ struct MarchStats {
   unsigned cnt = 0;
   unsigned isum_all = 0, isum_fg = 0;
   double fsum_all = 0.0, fsum_fg = 0.0;
+  unsigned bad = 0;  // float32 pixels: a pixel whose log(1 + x) is not finite was seen
   __device__ __forceinline__ void add(float f, float cutoff) {
+    if (IN_KIND != 0) bad |= (f > -1.0f && f <= 3.402823466e38f) ? 0u : 1u;  // false for NaN as well
     if (IN_KIND == 0) {
       const unsigned u = (unsigned)f;
       isum_all += u;
@@ -782,6 +786,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     s_all = wave_sum_f64(s_all);
     s_fg = wave_sum_f64(s_fg);
     const unsigned cnt = __reduce_add_sync(~0ull, st.cnt);
+    const bool bad_any = (IN_KIND == 1) && __any(st.bad != 0u) != 0;
     if (lane == 0) {
       PlaneStats* ps = a.stats + plane;
       if (s_all != 0.0) atomicAdd(&ps->sum_all, s_all);
@@ -789,6 +794,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
         atomicAdd(&ps->sum_fg, s_fg);
         atomicAdd(&ps->cnt_fg, (unsigned long long)cnt);
       }
+      if (IN_KIND == 1 && bad_any) atomicOr(&ps->flags, 1ull);
     }
   }
 }

@@ -20,7 +20,7 @@ STAGE_APPROX, STAGE_DETAIL = 0, 1
 STREAM_COMPUTE, STREAM_UPLOAD, STREAM_DOWNLOAD = 0, 1, 2
 COMM_ID_BYTES = 128
 _ERRORS = {-1: "DSX_EINVAL", -2: "DSX_ENOPLAN", -3: "DSX_EHIP", -4: "DSX_ENOMEM", -5: "DSX_ELIMIT",
-           -6: "DSX_ECOMM", -7: "DSX_EIO"}  # fmt: skip
+           -6: "DSX_ECOMM", -7: "DSX_EIO", -8: "DSX_EVALUE"}  # fmt: skip
 
 # every symbol include/dsx.h declares (tests/test_host_native.py checks the list against the header)
 EXPORTED_SYMBOLS = [
@@ -243,6 +243,8 @@ class DestripeEngine:
     def _check(self, rc):
         if rc != 0:
             msg = self._lib.dsx_last_error(self._ctx)
+            if rc == -8:  # DSX_EVALUE: the reference's own exception type and message (numpy.histogram)
+                raise ValueError(msg.decode() if msg else "autodetected range of [nan, nan] is not finite")
             raise DsxError(rc, msg.decode() if msg else "")
 
     def close(self):

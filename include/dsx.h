@@ -43,6 +43,8 @@ extern "C" {
 #define DSX_ELIMIT (-5)   /* plane exceeds an implementation limit                  */
 #define DSX_ECOMM (-6)    /* RCCL error / communicator not initialised              */
 #define DSX_EIO (-7)      /* chunk file could not be read / written                  */
+#define DSX_EVALUE (-8)   /* a float32 pixel is NaN, infinite or <= -1: the reference raises ValueError from
+                             numpy.histogram inside threshold_otsu (filtering.py:188); dsx_run_host only      */
 
 /* plane element types */
 #define DSX_U16 0 /* uint16 pixels (TIFF path, destriper.py:172-200)                 */

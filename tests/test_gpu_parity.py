@@ -577,3 +577,25 @@ def test_otsu_tie_plane(engine, capsys):
     bad[1] = float(centres[int(np.argmax(var)) + 3])
     with pytest.raises(AssertionError):
         parity_util.find_otsu_ties(bad, stages)
+
+
+@pytest.mark.parametrize("poison", [np.nan, np.inf, -2.0, -1.0])
+def test_invalid_float_pixels_raise_like_the_reference(poison):
+    """A float32 plane with a pixel whose log(1 + x) is not finite: the reference dies in numpy.histogram inside
+    threshold_otsu (ValueError: autodetected range of [nan, nan] is not finite; checked against the real reference
+    for NaN, inf, -2 and -1 with ``level=None``).  The engine flags such pixels in the forward kernel and the host-buffer
+    call raises the same exception type with the same message; the planes around it are not affected afterwards."""
+    planes = synth.synthetic_bank(3, 96, 128).astype(np.float32)
+    bad = planes.copy()
+    bad[1, 40, 50] = poison
+    with pytest.raises(ValueError, match="autodetected range of .* is not finite"):
+        filtering.destripe_planes(bad, "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT,
+                                  out_dtype=np.float32, max_batch=3)
+    # -0.5 is legal (log(0.5)), and a clean batch right after the failed one is processed normally
+    ok = planes.copy()
+    ok[1, 40, 50] = -0.5
+    out = filtering.destripe_planes(ok, "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT,
+                                    out_dtype=np.float32, max_batch=3)
+    assert np.isfinite(out).all()
+    which, _, _, ref, _ = oracle_plane(ok[1])
+    assert _rel(out[1], ref).max() < 1e-3  # one odd pixel: no flip accounting here, just "the same picture"
