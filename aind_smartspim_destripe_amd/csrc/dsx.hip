@@ -4,6 +4,7 @@
 // HIP streams; no host synchronisation inside):
 //   k_zero3  ->  k_fwd_march x L  ->  k_hist x L  ->  k_otsu  ->  k_rowfilter x L
 //   ->  k_inv_march<pyramid> x (L-1)  ->  k_inv_march<final>
+// A wavelet other than db3 (dsx_set_wavelet) swaps k_fwd_gen / k_inv_gen (dsx_wavelet.h) in for the marching kernels.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <math.h>
@@ -18,6 +19,7 @@
 #include "../../include/dsx.h"
 #include "dsx_kernels.h"
 #include "dsx_retile.h"
+#include "dsx_wavelet.h"
 #include "dsx_plan.h"
 #include "dsx_io.h"
 
@@ -77,6 +79,12 @@ struct dsx_ctx {
   bool profiling = false;
   std::vector<ProfRec> prof;
   size_t workspace_bytes = 0;
+  // filter bank given by dsx_set_wavelet (wl_len == 0: db3, the specialised marching kernels)
+  int wl_len = 0;          // bank in use by the current plan
+  int wl_bank_len = 0;     // bank given by the last dsx_set_wavelet
+  bool wl_set = false;
+  float wl[4][dsx::kMaxTaps] = {};       // dec_lo, dec_hi, rec_lo, rec_hi of the current plan
+  float wl_bank[4][dsx::kMaxTaps] = {};  // ... of the last dsx_set_wavelet
   int ablate = 0;  // DSX_ABLATE environment variable: row-filter phase ablation, diagnosis only
   // sub-cohort streams: a cohort is split into parts that run their launch chains concurrently, so that
   // latency-bound (march) and compute-bound (row filter) kernels of different parts overlap on the chip
@@ -297,7 +305,9 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   // ---- forward transform ------------------------------------------------------------------
   // levels 1 + 2 in one kernel when the plane allows it (aa_1 never leaves the chip)
   static const bool no_fuse = getenv("DSX_NO_FUSE") && atoi(getenv("DSX_NO_FUSE")) != 0;
-  const bool fuse12 = !no_fuse && L >= 2 && (p.W % 4) == 0 && (p.lv[0].ldin % 4) == 0 && p.lv[0].h >= 16 &&
+  // any wavelet but db3: tap-count-generic level kernels, one launch per level, nothing fused
+  const bool generic = ctx->wl_len > 0 && L > 0;
+  const bool fuse12 = !generic && !no_fuse && L >= 2 && (p.W % 4) == 0 && (p.lv[0].ldin % 4) == 0 && p.lv[0].h >= 16 &&
                       p.lv[0].w >= 16;
   static const bool no_fuse_inv = getenv("DSX_NO_FUSE_INV") && atoi(getenv("DSX_NO_FUSE_INV")) != 0;
   const bool fuse21 = fuse12 && !no_fuse_inv;
@@ -324,9 +334,40 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     DSX_HIP(hipGetLastError());
     return DSX_OK;
   };
+  // DSX_SKIP_COARSE=k (diagnosis only, results are wrong): no launch for levels with index >= k -- the
+  // time the chain would take if the coarse levels were free
+  static const int skip_from = getenv("DSX_SKIP_COARSE") ? atoi(getenv("DSX_SKIP_COARSE")) : 1000;
   for (int l = 0; l < L; ++l) {
     if (fuse12 && l == 1) continue;
+    if (l >= skip_from) continue;
     const dsx::LevelPlan& lp = p.lv[l];
+    if (generic) {
+      dsx::GenFwdArgs g;
+      memset(&g, 0, sizeof(g));
+      g.in = d_in;
+      g.in_plane_stride = (long long)p.H * p.W;
+      g.ws = v.ws;
+      g.ws_plane_stride = p.plane_floats;
+      g.in_off = (l > 0) ? p.lv[l - 1].aa_off : 0;
+      g.H = lp.hin; g.W = lp.win; g.ldin = lp.ldin;
+      g.aa_off = lp.aa_off; g.da_off = lp.da_off;
+      g.h = lp.h; g.w = lp.w; g.ld = lp.ld; g.lda = lp.lda;
+      g.minmax = v.minmax;
+      g.lvl = l; g.L = L;
+      g.stats = v.stats;
+      g.fg_cutoff = ctx->fg_cutoff;
+      g.F = ctx->wl_len;
+      memcpy(g.lo, ctx->wl[0], sizeof(float) * ctx->wl_len);
+      memcpy(g.hi, ctx->wl[1], sizeof(float) * ctx->wl_len);
+      const dim3 gg((lp.w + dsx::kGenTW - 1) / dsx::kGenTW, (lp.h + dsx::kGenTH - 1) / dsx::kGenTH, nb);
+      const size_t smem = dsx::gen_fwd_lds_bytes(g.F);
+      LaunchScope ls(ctx, l == 0 ? KC_FWD1 : KC_FWD);
+      if (l > 0) hipLaunchKernelGGL(dsx::k_fwd_gen<2>, gg, dim3(256), smem, s, g);
+      else if (in_dtype == DSX_U16) hipLaunchKernelGGL(dsx::k_fwd_gen<0>, gg, dim3(256), smem, s, g);
+      else hipLaunchKernelGGL(dsx::k_fwd_gen<1>, gg, dim3(256), smem, s, g);
+      DSX_HIP(hipGetLastError());
+      continue;
+    }
     dsx::Fwd1Args f;
     memset(&f, 0, sizeof(f));
     f.in = d_in;
@@ -383,7 +424,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   }
 
   // ---- thresholds -----------------------------------------------------------------------------
-  for (int l = split ? 2 : 0; l < L; ++l)
+  for (int l = split ? 2 : 0; l < L && l < skip_from; ++l)
     if (int rc = hist_level(l, s)) return rc;
   if (split) DSX_HIP(hipStreamWaitEvent(s, v.ev[1], 0));  // histograms of levels 1, 2 (helper stream)
   if (L > 0) {
@@ -418,7 +459,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     DSX_HIP(hipEventRecord(v.ev[2], s));                  // thresholds are known
     DSX_HIP(hipStreamWaitEvent(v.helper, v.ev[2], 0));
   }
-  for (int l = 0; l < L; ++l) {
+  for (int l = 0; l < L && l < skip_from; ++l) {
     hipStream_t rs = (split_inv && l < 2) ? v.helper : s;
     const dsx::LevelPlan& lp = p.lv[l];
     dsx::RowArgs a;
@@ -453,6 +494,46 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   // level-2 synthesis inside the final kernel when the plane allows it (c_1 never leaves the chip): fuse21
   for (int l = L - 1; l >= (L > 0 ? 0 : -1); --l) {
     if (fuse21 && l == 1) continue;
+    if (l >= skip_from) continue;
+    if (generic) {
+      dsx::GenInvArgs g;
+      memset(&g, 0, sizeof(g));
+      const dsx::LevelPlan& lp = p.lv[l];
+      g.ws = v.ws;
+      g.ws_plane_stride = p.plane_floats;
+      g.c_off = lp.aa_off; g.d_off = lp.da_off;
+      g.hc = lp.h; g.wc = lp.w; g.ldc = lp.lda; g.ldd = lp.ld;
+      g.has_c = (l < L - 1) ? 1 : 0;
+      g.has_pyr = 1;
+      g.F = ctx->wl_len;
+      memcpy(g.lo, ctx->wl[2], sizeof(float) * ctx->wl_len);
+      memcpy(g.hi, ctx->wl[3], sizeof(float) * ctx->wl_len);
+      const bool last_g = (l == 0);
+      if (!last_g) {
+        const dsx::LevelPlan& lo = p.lv[l - 1];
+        g.out_off = lo.aa_off;
+        g.hout = lo.h; g.wout = lo.w; g.ldout = lo.lda;
+      } else {
+        g.img = d_in;
+        g.img_plane_stride = (long long)p.H * p.W;
+        g.H = p.H; g.W = p.W;
+        g.out = d_out;
+        g.out_plane_stride = (long long)p.Hout * p.Wout;
+        g.hout = p.Hout; g.wout = p.Wout;
+        g.out_dtype = (out_dtype == DSX_U16) ? 0 : 1;
+        g.flat = ctx->d_flat;
+        g.dark = ctx->d_dark;
+        g.dark_ld = ctx->dark_w;
+      }
+      const dim3 gg((g.wout + dsx::kGenOW - 1) / dsx::kGenOW, (g.hout + dsx::kGenOH - 1) / dsx::kGenOH, nb);
+      const size_t smem = dsx::gen_inv_lds_bytes(g.F);
+      LaunchScope ls(ctx, last_g ? KC_FINAL : KC_INV);
+      if (!last_g) hipLaunchKernelGGL(dsx::k_inv_gen<2>, gg, dim3(256), smem, s, g);
+      else if (in_dtype == DSX_U16) hipLaunchKernelGGL(dsx::k_inv_gen<0>, gg, dim3(256), smem, s, g);
+      else hipLaunchKernelGGL(dsx::k_inv_gen<1>, gg, dim3(256), smem, s, g);
+      DSX_HIP(hipGetLastError());
+      continue;
+    }
     dsx::FinalArgs f;
     memset(&f, 0, sizeof(f));
     f.ws = v.ws;
@@ -700,12 +781,27 @@ int dsx_plan(dsx_ctx* ctx, int height, int width, int max_batch, const dsx_cfg* 
 
   const dsx_cfg* src[2] = {no_cells_config, cells_config};  // index 1 == cells_config
   for (int c = 0; c < 2; ++c) {
-    if (src[c]->wavelet != DSX_WAVELET_DB3) return fail(ctx, DSX_EINVAL, "only wavelet db3 is implemented");
+    // both configs run through ONE decomposition (the config is only decided once the level-1 statistic is known)
+    if (src[c]->wavelet != DSX_WAVELET_DB3 && src[c]->wavelet != DSX_WAVELET_BANK)
+      return fail(ctx, DSX_EINVAL, "unknown wavelet id");
+    if (src[c]->wavelet != src[0]->wavelet)
+      return fail(ctx, DSX_EINVAL, "cells_config and no_cells_config must name the same wavelet");
     ctx->cfg[c].level = src[c]->level;
     ctx->cfg[c].sigma = src[c]->sigma;
     ctx->cfg[c].max_threshold = src[c]->max_threshold;
   }
-  const std::string perr = dsx::build_plan(height, width, ctx->cfg, ctx->plan);
+  const bool bank = src[0]->wavelet == DSX_WAVELET_BANK;
+  if (bank && !ctx->wl_set) return fail(ctx, DSX_EINVAL, "DSX_WAVELET_BANK without dsx_set_wavelet");
+  ctx->wl_len = bank ? ctx->wl_bank_len : 0;
+  if (bank) {
+    memcpy(ctx->wl, ctx->wl_bank, sizeof(ctx->wl));
+    // the level kernels stage their patches in dynamic LDS: up to 110 KB at 104 taps
+    const void* fns[6] = {(const void*)dsx::k_fwd_gen<0>, (const void*)dsx::k_fwd_gen<1>, (const void*)dsx::k_fwd_gen<2>,
+                          (const void*)dsx::k_inv_gen<0>, (const void*)dsx::k_inv_gen<1>, (const void*)dsx::k_inv_gen<2>};
+    for (const void* fn : fns)
+      DSX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  const std::string perr = dsx::build_plan(height, width, ctx->cfg, ctx->plan, bank ? ctx->wl_bank_len : dsx::kFilterLen);
   if (!perr.empty()) {
     const bool limit = perr.find("too") != std::string::npos;
     return fail(ctx, limit ? DSX_ELIMIT : DSX_EINVAL, perr);
@@ -756,6 +852,23 @@ int dsx_plan(dsx_ctx* ctx, int height, int width, int max_batch, const dsx_cfg* 
   ctx->planned = true;
   ctx->last_n = 0;
   return DSX_OK;
+}
+
+int dsx_set_wavelet(dsx_ctx* ctx, const double* dec_lo, const double* dec_hi, const double* rec_lo,
+                    const double* rec_hi, int len) {
+  if (!ctx) return DSX_EINVAL;
+  if (!dec_lo || !dec_hi || !rec_lo || !rec_hi) return fail(ctx, DSX_EINVAL, "filter pointer is NULL");
+  if (len < 2 || (len & 1)) return fail(ctx, DSX_EINVAL, "wavelet filters must have an even number (>= 2) of taps");
+  if (len > dsx::kMaxTaps) return fail(ctx, DSX_ELIMIT, "wavelet filters are longer than the kernels take");
+  const double* src[4] = {dec_lo, dec_hi, rec_lo, rec_hi};
+  for (int f = 0; f < 4; ++f)
+    for (int t = 0; t < len; ++t) {
+      if (!(fabs(src[f][t]) < 1e30)) return fail(ctx, DSX_EINVAL, "wavelet filter coefficient is not finite");
+      ctx->wl_bank[f][t] = (float)src[f][t];
+    }
+  ctx->wl_bank_len = len;
+  ctx->wl_set = true;
+  return DSX_OK;  // takes effect at the next dsx_plan whose configs carry DSX_WAVELET_BANK
 }
 
 int dsx_set_shading_device(dsx_ctx* ctx, const float* d_flat, const float* d_dark, int dark_h,

@@ -21,7 +21,7 @@ namespace dsx {
 
 constexpr int kPlanMaxLevels = 16;
 constexpr int kPlanMaxPasses = 16;
-constexpr int kFilterLen = 6;           // db3
+constexpr int kFilterLen = 6;           // db3 (the default filter length of build_plan)
 constexpr int kMaxFftLen = 64 * 36;     // largest row-filter kernel instantiation (CPL = 36)
 
 struct HostCfg {
@@ -57,9 +57,10 @@ struct Plan {
   std::vector<C32> consts;     // twiddles + gain tables
 };
 
-inline int dwt_max_level(int n) {
-  if (n < kFilterLen - 1) return 0;
-  int l = (int)floor(log2((double)n / (kFilterLen - 1.0)));
+// pywt.dwt_max_level(data_len, filter_len)
+inline int dwt_max_level(int n, int filter_len = kFilterLen) {
+  if (filter_len < 2 || n < filter_len - 1) return 0;
+  int l = (int)floor(log2((double)(n / (filter_len - 1))));
   return l < 0 ? 0 : l;
 }
 
@@ -195,8 +196,10 @@ inline std::vector<double> idft_even(const std::vector<double>& g) {
 }
 
 // Build the plan.  Returns "" or an error text.
-inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p) {
+// filter_len: taps of the wavelet's filters (6 = db3; other lengths run the kernels of dsx_wavelet.h)
+inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p, int filter_len = kFilterLen) {
   if (H < 1 || W < 1) return "plane must be at least 1x1";
+  if (filter_len < 2 || (filter_len & 1)) return "wavelet filters must have an even number (>= 2) of taps";
   for (int c = 0; c < 2; ++c) {
     if (!(cfg[c].sigma > 0)) return "sigma must be positive";
     if (cfg[c].level < -1) return "Level value is too low . Minimum level is 0.";
@@ -204,7 +207,7 @@ inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p) {
   p = Plan();
   p.H = H;
   p.W = W;
-  const int max_level = std::min(dwt_max_level(H), dwt_max_level(W));
+  const int max_level = std::min(dwt_max_level(H, filter_len), dwt_max_level(W, filter_len));
   for (int c = 0; c < 2; ++c) p.cfg_levels[c] = cfg[c].level < 0 ? max_level : cfg[c].level;
   p.L = std::max(p.cfg_levels[0], p.cfg_levels[1]);
   if (p.L > kPlanMaxLevels) return "too many decomposition levels";
@@ -222,8 +225,8 @@ inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p) {
   for (int l = 0; l < p.L; ++l) {
     LevelPlan& lp = p.lv[l];
     lp.hin = hin; lp.win = win; lp.ldin = ldin;
-    lp.h = (hin + kFilterLen - 1) / 2;
-    lp.w = (win + kFilterLen - 1) / 2;
+    lp.h = (hin + filter_len - 1) / 2;
+    lp.w = (win + filter_len - 1) / 2;
     // da rows: >= 4 spare columns so that the synthesis kernels may load 4 coefficients past the end;
     // aa rows: logical column j lives at aa_off + i * lda + j, j in [-4, w + 8): the analysis kernel
     // stores the half-sample symmetric extension there, so the next level loads aligned groups only

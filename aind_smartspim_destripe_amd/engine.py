@@ -10,12 +10,15 @@ import os
 
 import numpy as np
 
+from . import wavelets
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DSX_LIB overrides the library path (A/B runs of two builds inside one GPU session)
 LIB_PATH = os.environ.get("DSX_LIB") or os.path.join(_HERE, "_lib", "libdsx_hip.so")
 
 DSX_U16, DSX_F32 = 0, 1
 DSX_WAVELET_DB3 = 3
+DSX_WAVELET_BANK = 0  # filter bank handed over with dsx_set_wavelet
 STAGE_APPROX, STAGE_DETAIL = 0, 1
 STREAM_COMPUTE, STREAM_UPLOAD, STREAM_DOWNLOAD = 0, 1, 2
 COMM_ID_BYTES = 128
@@ -24,7 +27,7 @@ _ERRORS = {-1: "DSX_EINVAL", -2: "DSX_ENOPLAN", -3: "DSX_EHIP", -4: "DSX_ENOMEM"
 
 # every symbol include/dsx.h declares (tests/test_host_native.py checks the list against the header)
 EXPORTED_SYMBOLS = [
-    "dsx_init", "dsx_destroy", "dsx_last_error", "dsx_device_count", "dsx_plan", "dsx_plan_info",
+    "dsx_init", "dsx_destroy", "dsx_last_error", "dsx_device_count", "dsx_plan", "dsx_plan_info", "dsx_set_wavelet",
     "dsx_set_shading_device", "dsx_constants_device", "dsx_run_host", "dsx_run_device", "dsx_sync",
     "dsx_malloc", "dsx_free", "dsx_memcpy_h2d", "dsx_memcpy_d2h", "dsx_memcpy_d2d",
     "dsx_timer_start", "dsx_timer_stop", "dsx_profile_enable", "dsx_profile_read",
@@ -118,6 +121,7 @@ def load_library(path=None):
     lib.dsx_get_thresholds.argtypes = [vp, i32, i32, f32p, f32p]
     lib.dsx_get_level.argtypes = [vp, i32, i32, i32, vp]
     lib.dsx_set_stop_after.argtypes = [vp, i32]
+    lib.dsx_set_wavelet.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 4 + [i32]
     lib.dsx_bricks_to_planes_u16.argtypes = [vp, vp, vp] + [i32] * 7
     lib.dsx_planes_to_bricks_u16.argtypes = [vp, vp, vp] + [i32] * 7
     lib.dsx_downsample2_u16.argtypes = [vp, vp, vp, i32, i32, i32]
@@ -150,13 +154,16 @@ def load_library(path=None):
     return lib
 
 
+def _wavelet_key(cfg):
+    w = cfg.get("wavelet", "db3")
+    return w.lower() if isinstance(w, str) else w
+
+
 def _as_cfg(cfg):
     """Reference config dict {"wavelet","level","sigma","max_threshold"} -> C struct."""
-    wavelet = cfg.get("wavelet", "db3")
-    if wavelet != "db3":
-        raise ValueError("only wavelet 'db3' is implemented (production setting, run_capsule.py:374-390)")
+    wid = DSX_WAVELET_DB3 if _wavelet_key(cfg) == "db3" and not os.environ.get("DSX_GENERIC_DB3") else DSX_WAVELET_BANK
     level = cfg.get("level", 0)
-    return _Cfg(DSX_WAVELET_DB3, -1 if level is None else int(level), float(cfg.get("sigma", 64)),
+    return _Cfg(wid, -1 if level is None else int(level), float(cfg.get("sigma", 64)),
                 float(cfg.get("max_threshold", 4)))  # fmt: skip
 
 
@@ -262,6 +269,17 @@ class DestripeEngine:
     def plan(self, height, width, cells_config, no_cells_config, microscope_high_int=2700,
              max_batch=32, flatfield=None, darkfield=None):  # fmt: skip
         cells, no_cells = _as_cfg(cells_config), _as_cfg(no_cells_config)
+        # Both configs go through ONE decomposition: which config a plane takes is only known once the
+        # statistic fused into the level-1 analysis is (filtering.py:455-462 decides before it transforms).
+        if _wavelet_key(cells_config) != _wavelet_key(no_cells_config):
+            raise ValueError("cells_config and no_cells_config must name the same wavelet")
+        if cells.wavelet == DSX_WAVELET_BANK:  # anything but db3: hand the filter bank over (DSX_GENERIC_DB3: db3 too)
+            bank = [np.ascontiguousarray(f, dtype=np.float64) for f in wavelets.filter_bank(_wavelet_key(cells_config))]
+            dp = ctypes.POINTER(ctypes.c_double)
+            rc = self._lib.dsx_set_wavelet(self._ctx, *[f.ctypes.data_as(dp) for f in bank], len(bank[0]))
+            if rc == -1:
+                raise ValueError(self._lib.dsx_last_error(self._ctx).decode())
+            self._check(rc)
 
         def call(flat_p, dark_p, dark_h, dark_w):
             rc = self._lib.dsx_plan(self._ctx, int(height), int(width), int(max_batch), ctypes.byref(cells),

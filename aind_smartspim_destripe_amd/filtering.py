@@ -25,8 +25,8 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import engine as _engine
+from . import wavelets as _wavelets
 
-_FILTER_LEN = 6  # db3
 
 
 # ---------------------------------------------------------------------------------------------
@@ -184,19 +184,21 @@ def _cfg_key(cfg):
             float(cfg.get("max_threshold", 4)))  # fmt: skip
 
 
-def _max_level(shape):
+def _max_level(shape, filter_len=6):
+    """``pywt.dwt_max_level`` over both axes (6 taps: db3)."""
+
     def one(n):
-        if n < _FILTER_LEN - 1:
+        if n < filter_len - 1:
             return 0
-        return max(0, int(math.floor(math.log2(n / (_FILTER_LEN - 1.0)))))
+        return max(0, int(math.floor(math.log2(n // (filter_len - 1)))))
 
     return min(one(shape[0]), one(shape[1]))
 
 
 def _warn_levels(shape, *cfgs):
     """pywt.wavedec2 warns (does not fail) when ``level`` exceeds the maximum useful level."""
-    mx = _max_level(shape)
     for cfg in cfgs:
+        mx = _max_level(shape, _wavelets.filter_length(cfg.get("wavelet", "db3")))
         lvl = cfg.get("level", 0)
         if lvl is not None and lvl > mx:
             warnings.warn(
@@ -253,7 +255,8 @@ def log_space_fft_filtering(
     sigma: Optional[int] = 64,
     max_threshold: Optional[int] = 4,
 ):
-    """``filtering.py:139-224`` on the GPU: log -> db3 DWT -> per-level Otsu mask, row-median
+    """``filtering.py:139-224`` on the GPU: log -> DWT (any PyWavelets discrete wavelet but ``dmey``; ``db3``,
+    the production setting, has specialised kernels) -> per-level Otsu mask, row-median
     in-paint and packed-index gaussian notch on cH -> inverse DWT -> ``exp(.) + 1.0``.
 
     Returns float64 ``[H + H % 2, W + W % 2]`` like the reference (computed in float32 on the

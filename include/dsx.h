@@ -50,8 +50,11 @@ extern "C" {
 #define DSX_U16 0 /* uint16 pixels (TIFF path, destriper.py:172-200)                 */
 #define DSX_F32 1 /* float32 pixels (Zarr path, zarr_destriper.py:1049)              */
 
-/* wavelet ids (only db3 is used in production, run_capsule.py:374-390) */
+/* wavelet ids: db3 is the production setting (run_capsule.py:374-390) and has its own kernels; any other
+ * wavelet the reference's config may name (pywt.wavedec2(..., wavelet=...), filtering.py:176) is handed over
+ * as its filter bank with dsx_set_wavelet and selected with DSX_WAVELET_BANK                              */
 #define DSX_WAVELET_DB3 3
+#define DSX_WAVELET_BANK 0
 
 /* stage buffers for dsx_get_level() */
 #define DSX_STAGE_APPROX 0 /* aa_l (before the inverse pass overwrites it with c_l)   */
@@ -61,7 +64,7 @@ typedef struct dsx_ctx dsx_ctx;
 
 /* One config dict of the reference: {"wavelet","level","sigma","max_threshold"}. */
 typedef struct dsx_cfg {
-  int32_t wavelet;     /* DSX_WAVELET_DB3                                             */
+  int32_t wavelet;     /* DSX_WAVELET_DB3 or DSX_WAVELET_BANK; both configs the same   */
   int32_t level;       /* -1 == None (maximum level), 0 == filter is the identity + 2 */
   float sigma;         /* > 0                                                         */
   float max_threshold; /* upper bound of the Otsu threshold                           */
@@ -92,6 +95,12 @@ int dsx_plan(dsx_ctx* ctx, int height, int width, int max_batch, const dsx_cfg* 
              const dsx_cfg* no_cells_config, double microscope_high_int, const float* flat,
              const float* dark, int dark_h, int dark_w);
 int dsx_plan_info(const dsx_ctx* ctx, dsx_plan_info_t* info);
+/* The four filters of a pywt.Wavelet (dec_lo, dec_hi, rec_lo, rec_hi; `len` taps each, even, 2 ... 104) for
+ * plans whose configs carry DSX_WAVELET_BANK: what the reference passes by name to pywt.wavedec2 / waverec2
+ * (filtering.py:176, 221).  Mode 'symmetric', perfect-reconstruction banks only (the engine reconstructs the
+ * correction, not the plane).  Takes effect at the next dsx_plan.                                          */
+int dsx_set_wavelet(dsx_ctx* ctx, const double* dec_lo, const double* dec_hi, const double* rec_lo,
+                    const double* rec_hi, int len);
 /* Same, with the shading planes already in device memory (e.g. after an RCCL broadcast). */
 int dsx_set_shading_device(dsx_ctx* ctx, const float* d_flat, const float* d_dark, int dark_h,
                            int dark_w);

@@ -60,13 +60,27 @@ DB3_DEC_HI = np.array(
 DB3_REC_LO = DB3_DEC_LO[::-1].copy()
 DB3_REC_HI = DB3_DEC_HI[::-1].copy()
 FILTER_LEN = 6
+DB3_BANK = (DB3_DEC_LO, DB3_DEC_HI, DB3_REC_LO, DB3_REC_HI)
+
+
+def as_bank(wavelet):
+    """``"db3"`` or a filter bank ``(dec_lo, dec_hi, rec_lo, rec_hi)`` (the attributes of a ``pywt.Wavelet``; the
+    tests take them from the table written by ``oracle/make_wavelet_table.py``) -> four float64 arrays."""
+    if wavelet is None or (isinstance(wavelet, str) and wavelet == "db3"):
+        return DB3_BANK
+    if isinstance(wavelet, str):
+        raise ValueError("the oracle knows 'db3' by name; pass the filter bank of any other wavelet")
+    bank = tuple(np.asarray(f, dtype=np.float64) for f in wavelet)
+    if len(bank) != 4 or len({len(f) for f in bank}) != 1 or len(bank[0]) % 2:
+        raise ValueError("a filter bank is (dec_lo, dec_hi, rec_lo, rec_hi) of one even length")
+    return bank
 
 
 def dwt_max_level(data_len, filter_len=FILTER_LEN):
     """``pywt.dwt_max_level``: floor(log2(data_len / (filter_len - 1))), never below 0."""
     if data_len < filter_len - 1:
         return 0
-    return max(0, int(math.floor(math.log2(data_len / (filter_len - 1.0)))))
+    return max(0, int(math.floor(math.log2(data_len // (filter_len - 1)))))
 
 
 def dwt_coeff_len(n, filter_len=FILTER_LEN):
@@ -84,17 +98,18 @@ def _symmetric_index(idx, n):
 def dwt_axis(x, filt, axis):
     """1-D analysis along ``axis`` (PyWavelets C ``dwt_axis``, mode symmetric).
 
-    out[i] = sum_k filt[k] * x~[2 i + 1 - k],  i = 0 .. (N + 5)//2 - 1, where x~ is the half-sample
+    out[i] = sum_k filt[k] * x~[2 i + 1 - k],  i = 0 .. (N + F - 1)//2 - 1, where x~ is the half-sample
     symmetric extension of x.  Computed in the dtype of ``x`` (float32 stays float32, as in pywt).
     """
     x = np.moveaxis(x, axis, -1)
     n = x.shape[-1]
-    m = dwt_coeff_len(n)
+    flen = len(filt)
+    m = dwt_coeff_len(n, flen)
     f = filt.astype(x.dtype)
-    pos = 2 * np.arange(m)[:, None] + 1 - np.arange(FILTER_LEN)[None, :]  # [m, 6]
+    pos = 2 * np.arange(m)[:, None] + 1 - np.arange(flen)[None, :]  # [m, F]
     idx = _symmetric_index(pos, n)
     out = np.zeros(x.shape[:-1] + (m,), dtype=x.dtype)
-    for k in range(FILTER_LEN):
+    for k in range(flen):
         out += f[k] * x[..., idx[:, k]]
     return np.moveaxis(out, -1, axis)
 
@@ -102,53 +117,57 @@ def dwt_axis(x, filt, axis):
 def idwt_axis(a, d, rec_lo, rec_hi, axis):
     """1-D synthesis along ``axis`` (PyWavelets C ``idwt_axis``, any non-periodization mode).
 
-    For M coefficients the output has 2 M - 4 samples:
-    out[2 p + b] = sum_{j=0..2} a[p + j] * rec_lo[4 - 2 j + b] + d[p + j] * rec_hi[4 - 2 j + b].
+    For M coefficients and F taps the output has 2 M - F + 2 samples:
+    out[2 p + b] = sum_{j < F/2} a[p + j] * rec_lo[F - 2 - 2 j + b] + d[p + j] * rec_hi[F - 2 - 2 j + b].
     """
     a = np.moveaxis(a, axis, -1)
     d = np.moveaxis(d, axis, -1)
     m = a.shape[-1]
-    n_out = 2 * m - FILTER_LEN + 2
+    flen = len(rec_lo)
+    n_out = 2 * m - flen + 2
     dt = np.result_type(a.dtype, d.dtype)
     out = np.zeros(a.shape[:-1] + (n_out,), dtype=dt)
-    p = m - 2  # number of (even, odd) output pairs
+    p = n_out // 2  # number of (even, odd) output pairs
     lo = rec_lo.astype(dt)
     hi = rec_hi.astype(dt)
     for b in (0, 1):
         acc = np.zeros(a.shape[:-1] + (p,), dtype=dt)
-        for j in range(3):
-            acc += a[..., j : j + p] * lo[4 - 2 * j + b] + d[..., j : j + p] * hi[4 - 2 * j + b]
+        for j in range(flen // 2):
+            t = flen - 2 - 2 * j + b
+            acc += a[..., j : j + p] * lo[t] + d[..., j : j + p] * hi[t]
         out[..., b::2] = acc
     return np.moveaxis(out, -1, axis)
 
 
-def dwt2(x):
+def dwt2(x, bank=DB3_BANK):
     """One 2-D analysis level: axis 0 first, then axis 1 (pywt ``dwtn`` order).
 
     Returns ``aa, (da, ad, dd)`` = cA, (cH, cV, cD).
     """
-    a0 = dwt_axis(x, DB3_DEC_LO, 0)
-    d0 = dwt_axis(x, DB3_DEC_HI, 0)
-    aa = dwt_axis(a0, DB3_DEC_LO, 1)
-    ad = dwt_axis(a0, DB3_DEC_HI, 1)
-    da = dwt_axis(d0, DB3_DEC_LO, 1)
-    dd = dwt_axis(d0, DB3_DEC_HI, 1)
+    dec_lo, dec_hi = bank[0], bank[1]
+    a0 = dwt_axis(x, dec_lo, 0)
+    d0 = dwt_axis(x, dec_hi, 0)
+    aa = dwt_axis(a0, dec_lo, 1)
+    ad = dwt_axis(a0, dec_hi, 1)
+    da = dwt_axis(d0, dec_lo, 1)
+    dd = dwt_axis(d0, dec_hi, 1)
     return aa, (da, ad, dd)
 
 
-def idwt2(aa, details):
+def idwt2(aa, details, bank=DB3_BANK):
     """One 2-D synthesis level (pywt ``idwtn``): axis 1 first, then axis 0; mixed dtypes upcast."""
     da, ad, dd = details
+    rec_lo, rec_hi = bank[2], bank[3]
     dt = np.result_type(aa.dtype, da.dtype, ad.dtype, dd.dtype)
     aa, da, ad, dd = (c.astype(dt, copy=False) for c in (aa, da, ad, dd))
-    a0 = idwt_axis(aa, ad, DB3_REC_LO, DB3_REC_HI, 1)
-    d0 = idwt_axis(da, dd, DB3_REC_LO, DB3_REC_HI, 1)
-    return idwt_axis(a0, d0, DB3_REC_LO, DB3_REC_HI, 0)
+    a0 = idwt_axis(aa, ad, rec_lo, rec_hi, 1)
+    d0 = idwt_axis(da, dd, rec_lo, rec_hi, 1)
+    return idwt_axis(a0, d0, rec_lo, rec_hi, 0)
 
 
-def resolve_level(shape, level):
+def resolve_level(shape, level, filter_len=FILTER_LEN):
     """Level selection of ``pywt.wavedec2`` (``_multilevel.py:_check_level``)."""
-    max_level = min(dwt_max_level(s) for s in shape[-2:])
+    max_level = min(dwt_max_level(s, filter_len) for s in shape[-2:])
     if level is None:
         return max_level
     if level < 0:
@@ -162,21 +181,21 @@ def resolve_level(shape, level):
     return level
 
 
-def wavedec2(x, level=None):
-    """``pywt.wavedec2(x, 'db3', level=level)``: ``[cA_L, (cH_L, cV_L, cD_L), ..., (cH_1, ...)]``."""
-    level = resolve_level(x.shape, level)
+def wavedec2(x, level=None, bank=DB3_BANK):
+    """``pywt.wavedec2(x, wavelet, level=level)``: ``[cA_L, (cH_L, cV_L, cD_L), ..., (cH_1, ...)]``."""
+    level = resolve_level(x.shape, level, len(bank[0]))
     coeffs = []
     a = x
     for _ in range(level):
-        a, det = dwt2(a)
+        a, det = dwt2(a, bank)
         coeffs.append(det)
     coeffs.append(a)
     coeffs.reverse()
     return coeffs
 
 
-def waverec2(coeffs):
-    """``pywt.waverec2(coeffs, 'db3')`` incl. the one-too-long trim (``_multilevel.py:333-335``)."""
+def waverec2(coeffs, bank=DB3_BANK):
+    """``pywt.waverec2(coeffs, wavelet)`` incl. the one-too-long trim (``_multilevel.py:333-335``)."""
     a = coeffs[0]
     for det in coeffs[1:]:
         d_shape = det[0].shape
@@ -184,7 +203,7 @@ def waverec2(coeffs):
             a = a[..., :-1, :]
         if a.shape[-1] == d_shape[-1] + 1:
             a = a[..., :-1]
-        a = idwt2(a, det)
+        a = idwt2(a, det, bank)
     return a
 
 
@@ -374,15 +393,14 @@ def log_space_fft_filtering(
     Stage list (``return_stages=True``) is ordered coarse -> fine like the reference loop;
     ``mask_overrides`` / ``otsu_overrides`` (tests only, same order, entries may be None): see :func:`filter_level`.
     """
-    if wavelet != "db3":
-        raise ValueError("the oracle restates db3 only (production wavelet, run_capsule.py:374-390)")
+    bank = as_bank(wavelet)
     input_image = np.asarray(input_image)
     if input_image.ndim != 2:
         raise ValueError("the oracle restates the 2-D plane path only")
     input_image_log = np.log(1.0 + input_image)
     if input_image_log.dtype == np.float16:
         input_image_log = input_image_log.astype(np.float32)
-    coeffs = wavedec2(input_image_log, level=level)
+    coeffs = wavedec2(input_image_log, level=level, bank=bank)
     approx, detail = coeffs[0], coeffs[1:]
     width_fraction = sigma / min(input_image.shape)
     stages = [] if return_stages else None
@@ -393,7 +411,7 @@ def log_space_fft_filtering(
                                    None if mask_overrides is None else mask_overrides[i],
                                    None if otsu_overrides is None else otsu_overrides[i])
         coeff_filtered.append((ch_filtered, cv, cd))
-    img_log_filtered = waverec2(coeff_filtered)
+    img_log_filtered = waverec2(coeff_filtered, bank)
     img_filtered = np.exp(img_log_filtered) + 1.0
     if return_stages:
         return img_filtered, stages

@@ -8,7 +8,7 @@ One such flip at level ``l``, coefficient row ``i`` changes Delta_l along that w
 and the low-pass are per-row operators) by up to the threshold itself -- 15 % of a pixel has been
 observed -- and reaches, through ``l`` db3 synthesis steps, the result rows
 
-    [2^l i - 4 (2^l - 1),  2^l i + 2^l - 1]      (all columns).
+    [2^l i - (F - 2) (2^l - 1),  2^l i + 2^l - 1]      (all columns; F = taps of the wavelet, 6 for db3).
 
 What the tests prove, per plane:
 
@@ -143,7 +143,7 @@ def find_otsu_ties(otsu_gpu, stages, ch_gpu=None):
     return overrides if any_tie else None
 
 
-def find_flips(deltas, stages, out_h):
+def find_flips(deltas, stages, out_h, filter_len=6):
     """Near-threshold coefficients whose mask bit differs between engine and oracle.
 
     ``deltas``: Delta per level of one plane (fine -> coarse); ``stages``: oracle stages (fine -> coarse).
@@ -167,13 +167,15 @@ def find_flips(deltas, stages, out_h):
         forced.append(np.where(flip, mask_gpu, mask_ref))
         s = 1 << (lv + 1)
         for i in np.nonzero(flip.any(axis=1))[0]:
-            lo, hi = s * int(i) - 4 * (s - 1), s * int(i) + s - 1
+            lo, hi = s * int(i) - (filter_len - 2) * (s - 1), s * int(i) + s - 1
             rows[max(lo, 0) : min(hi, out_h - 1) + 1] = True
     return (forced if sum(counts) else None), rows, counts
 
 
 def check_plane(out, img, deltas, what, cfg, max_flips, ref=None, stages=None, pos=None):
     """Proof obligations (a)-(e) of the module docstring for one plane.
+
+    ``cfg`` is what the ORACLE is called with: its ``"wavelet"`` is ``"db3"`` or a filter bank (tests/test_wavelets.py).
 
     ``out``: full engine result; ``img``: the input in the dtype regime the reference values were made in;
     ``ref``: reference values (full plane, or samples at ``pos = (sy, sx)``), default = the oracle's output.
@@ -192,7 +194,7 @@ def check_plane(out, img, deltas, what, cfg, max_flips, ref=None, stages=None, p
         ref_t, stages_c2f = orc.log_space_fft_filtering(img, return_stages=True, otsu_overrides=ties[::-1], **cfg)
         stages = stages_c2f[::-1]
         ref = ref_t if pos is None else ref_t[pos[0], pos[1]]
-    forced, rows_ok, flips = find_flips(deltas, stages, out.shape[0])
+    forced, rows_ok, flips = find_flips(deltas, stages, out.shape[0], len(orc.as_bank(cfg.get("wavelet", "db3"))[0]))
     for lv, (f, st) in enumerate(zip(flips, stages)):
         assert f <= max_flips(st["ch"].size), (what, "flips at level", lv, f)
     o = out if pos is None else out[pos[0], pos[1]]
