@@ -110,7 +110,7 @@ def golden_name(h, w):
     return "s{}".format(h) if h == w else "s{}x{}".format(h, w)
 
 
-def verify(engine, stack, d_out, h, w, batch, cohort, n_streams, shading):
+def verify(engine, stack, d_out, h, w, batch, cohort, n_streams, shading, wavelet="db3"):
     """Tie the timed configuration's output to the reference.  Returns (ok, details)."""
     details = {}
     ok = True
@@ -124,7 +124,7 @@ def verify(engine, stack, d_out, h, w, batch, cohort, n_streams, shading):
     if os.path.exists(gpath):
         g = np.load(gpath, allow_pickle=False)
         name = golden_name(h, w)
-        if name + "__k0__u16__sample" in g.files:
+        if name + "__k0__u16__sample" in g.files and wavelet == "db3":
             rs = np.random.RandomState(7)
             sy, sx = rs.randint(0, h, 4096), rs.randint(0, w, 4096)
             worst, n_off = 0, 0
@@ -147,7 +147,7 @@ def verify(engine, stack, d_out, h, w, batch, cohort, n_streams, shading):
             details["golden_samples_off_by_one"] = n_off
             details["golden_worst_count_diff"] = worst
         else:
-            details["golden_planes"] = "no golden vector for this shape"
+            details["golden_planes"] = "no golden vector for this shape / wavelet"
     # (2) one plane of every stream part, re-run alone on the main stream: must be bit-identical
     parts = n_streams
     nb = min(cohort, batch)
@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="slices per step per GPU")
     ap.add_argument("--shape", default="2048x2048", help="plane shape HxW (BASELINE configs: 2048x2048, 1800x1800, 1600x2000)")
     ap.add_argument("--shading", action="store_true", help="dark / flat-field correction fused into the last kernel")
+    ap.add_argument("--wavelet", default="db3", help="wavelet of both configs (db3 = production, specialised kernels; "
+                    "any other PyWavelets name runs the tap-count-generic level kernels; not the headline metric)")
     ap.add_argument("--cohort", type=int, default=int(os.environ.get("DSX_COHORT", "256")),
                     help="planes per launch chain (workspace size)")  # fmt: skip
     ap.add_argument("--cpu-planes", type=int, default=None,
@@ -219,13 +221,14 @@ def main():
 
     # CPU baseline first (rank 0, N = 1): its workers are spawned, which must not happen once this process holds the GPU
     cpu = None
-    if world == 1 and args.cpu_planes != 0:
+    if world == 1 and args.cpu_planes != 0 and args.wavelet == "db3":
         cpu = cpu_baseline(args.cpu_planes or 16 * args.cpu_procs, args.cpu_procs, H, W)
         log("[bench] cpu baseline: {}".format(cpu))
 
     engine = eng_mod.DestripeEngine(local)
     shading = synthetic_shading(H, W) if args.shading else None
-    info = engine.plan(H, W, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT,
+    info = engine.plan(H, W, dict(synth.CELLS_CONFIG, wavelet=args.wavelet), dict(synth.NO_CELLS_CONFIG, wavelet=args.wavelet),
+                       synth.ZARR_PATH_HIGH_INT,
                        max_batch=min(args.cohort, args.batch),
                        flatfield=None if shading is None else shading[0],
                        darkfield=None if shading is None else shading[1])  # fmt: skip
@@ -280,7 +283,7 @@ def main():
     n_streams = int(os.environ.get("DSX_STREAMS", "4"))
     verified, vdetails = (None, {"skipped": True})
     if not args.no_verify:
-        verified, vdetails = verify(engine, stack, d_out, H, W, args.batch, min(args.cohort, args.batch), n_streams, shading)
+        verified, vdetails = verify(engine, stack, d_out, H, W, args.batch, min(args.cohort, args.batch), n_streams, shading, args.wavelet)
         verified = bool(group.allreduce([1.0 if verified else 0.0], "min")[0] == 1.0)
 
     breakdown = None
@@ -306,7 +309,7 @@ def main():
                 with open(os.path.join(REPO, "profiles", name)) as f:
                     t = json.load(f)
                 if t.get("planes_per_step") == args.batch and t.get("shape", "2048x2048") == "{}x{}".format(H, W) \
-                        and bool(t.get("shading", False)) == bool(args.shading):
+                        and bool(t.get("shading", False)) == bool(args.shading) and args.wavelet == "db3":
                     traffic = int(t["hbm_bytes_per_step"])
                     traffic_source = "profiles/{} ({})".format(name, t.get("build", "build not recorded"))
                     break
@@ -326,9 +329,10 @@ def main():
             "verified": verified,
             "config": {
                 "workload": "batch of {} x {}x{} uint16 slices per GPU, log-space wavelet-FFT destripe "
-                            "(filter_stripes semantics, production cells/no-cells configs, high_int 2500{}), "
+                            "(filter_stripes semantics, production cells/no-cells configs, high_int 2500{}{}), "
                             "uint16 out, inputs resident in HBM".format(
-                                args.batch, H, W, ", dark/flat-field correction on" if args.shading else ""),
+                                args.batch, H, W, ", dark/flat-field correction on" if args.shading else "",
+                                "" if args.wavelet == "db3" else ", wavelet {} instead of db3".format(args.wavelet)),
                 "slices_per_gpu": args.batch,
                 "cohort": min(args.cohort, args.batch),
                 "sub_cohort_streams": n_streams,
