@@ -27,7 +27,7 @@ _ERRORS = {-1: "DSX_EINVAL", -2: "DSX_ENOPLAN", -3: "DSX_EHIP", -4: "DSX_ENOMEM"
 
 # every symbol include/dsx.h declares (tests/test_host_native.py checks the list against the header)
 EXPORTED_SYMBOLS = [
-    "dsx_init", "dsx_destroy", "dsx_last_error", "dsx_device_count", "dsx_plan", "dsx_plan_info", "dsx_set_wavelet",
+    "dsx_init", "dsx_destroy", "dsx_last_error", "dsx_device_count", "dsx_plan", "dsx_plan_info", "dsx_set_wavelet", "dsx_graph_stats",
     "dsx_set_shading_device", "dsx_constants_device", "dsx_run_host", "dsx_run_device", "dsx_sync",
     "dsx_malloc", "dsx_free", "dsx_memcpy_h2d", "dsx_memcpy_d2h", "dsx_memcpy_d2d",
     "dsx_timer_start", "dsx_timer_stop", "dsx_profile_enable", "dsx_profile_read",
@@ -121,6 +121,7 @@ def load_library(path=None):
     lib.dsx_get_thresholds.argtypes = [vp, i32, i32, f32p, f32p]
     lib.dsx_get_level.argtypes = [vp, i32, i32, i32, vp]
     lib.dsx_set_stop_after.argtypes = [vp, i32]
+    lib.dsx_graph_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.dsx_set_wavelet.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 4 + [i32]
     lib.dsx_bricks_to_planes_u16.argtypes = [vp, vp, vp] + [i32] * 7
     lib.dsx_planes_to_bricks_u16.argtypes = [vp, vp, vp] + [i32] * 7
@@ -317,6 +318,12 @@ class DestripeEngine:
                         dark.shape[0], dark.shape[1])  # fmt: skip
         self.info = info
         return info
+
+    def graph_stats(self):
+        """``(graph launches, captures)`` of this context (``dsx_graph_stats``)."""
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self._lib.dsx_graph_stats(self._ctx, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     @property
     def out_shape(self):

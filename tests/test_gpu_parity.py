@@ -599,3 +599,67 @@ def test_invalid_float_pixels_raise_like_the_reference(poison):
     assert np.isfinite(out).all()
     which, _, _, ref, _ = oracle_plane(ok[1])
     assert _rel(out[1], ref).max() < 1e-3  # one odd pixel: no flip accounting here, just "the same picture"
+
+
+def test_graph_replay_is_bit_identical_to_eager_launches(monkeypatch):
+    """DSX_GRAPH=1: unsplit cohorts are captured into a HIP graph at the second identical call and replayed afterwards
+    (dsx_graph_stats counts): every call returns the bits of the eager first one; a new plan, new shading planes or
+    other buffers start over; the host-buffer API (the per-slice filter_stripes calls) replays too."""
+    planes = synth.synthetic_bank(5, 200, 232)
+    monkeypatch.setenv("DSX_GRAPH", "1")
+    e = eng_mod.DestripeEngine(0)
+    try:
+        e.plan(200, 232, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT, max_batch=8)
+        d_in, d_out, d_cfg = e.alloc(planes.nbytes), e.alloc(planes.nbytes * 2), e.alloc(4 * 5)
+        d_in.upload(planes)
+        outs = []
+        for _ in range(4):
+            e.run_device(d_in, np.uint16, 5, d_out, np.float32, d_cfg)
+            e.sync()
+            outs.append((d_out.download((5, 200, 232), np.float32), d_cfg.download((5,), np.int32)))
+        launches, captures = e.graph_stats()
+        assert captures == 1 and launches == 3, (launches, captures)
+        for o, c in outs[1:]:
+            np.testing.assert_array_equal(o, outs[0][0])
+            np.testing.assert_array_equal(c, outs[0][1])
+        # another count through the same buffers is another graph; the first one is still there
+        for _ in range(3):
+            e.run_device(d_in, np.uint16, 3, d_out, np.float32, d_cfg)
+        e.sync()
+        np.testing.assert_array_equal(d_out.download((3, 200, 232), np.float32), outs[0][0][:3])
+        e.run_device(d_in, np.uint16, 5, d_out, np.float32, d_cfg)
+        e.sync()
+        assert e.graph_stats() == (launches + 3, 2)
+        np.testing.assert_array_equal(d_out.download((5, 200, 232), np.float32), outs[0][0])
+        # host-buffer calls go through the context's staging buffers: replayed from the third call on
+        before = e.graph_stats()
+        host = [e.run(planes[:2], out_dtype=np.float32) for _ in range(4)]
+        for h in host[1:]:
+            np.testing.assert_array_equal(h, host[0])
+        np.testing.assert_array_equal(host[0], outs[0][0][:2])
+        assert e.graph_stats()[0] >= before[0] + 2
+        # a new plan drops the graphs (they hold workspace addresses) and the results follow the new configs
+        cfg2 = dict(synth.CELLS_CONFIG, sigma=200)
+        e.plan(200, 232, cfg2, cfg2, synth.ZARR_PATH_HIGH_INT, max_batch=8)
+        new = []
+        for _ in range(3):
+            e.run_device(d_in, np.uint16, 5, d_out, np.float32, d_cfg)
+            e.sync()
+            new.append(d_out.download((5, 200, 232), np.float32))
+        np.testing.assert_array_equal(new[1], new[0])
+        np.testing.assert_array_equal(new[2], new[0])
+        assert not np.array_equal(new[0], outs[0][0])
+        ref = orc.log_space_fft_filtering(planes[1], **cfg2)
+        assert _rel(new[2][1], ref).max() < REL_TOL
+        # the default: a context that never captures gives the same bits
+        monkeypatch.delenv("DSX_GRAPH")
+        e2 = eng_mod.DestripeEngine(0)
+        try:
+            e2.plan(200, 232, cfg2, cfg2, synth.ZARR_PATH_HIGH_INT, max_batch=8)
+            eager = [e2.run(planes, out_dtype=np.float32) for _ in range(3)]
+            assert e2.graph_stats() == (0, 0)
+            np.testing.assert_array_equal(eager[2], new[0])
+        finally:
+            e2.close()
+    finally:
+        e.close()
