@@ -1452,9 +1452,10 @@ int dsx_comm_allreduce_f64(dsx_ctx* ctx, double* values, int n, int op) {
 
 /* ---- chunk files <-> staging memory on native threads (dsx_io.h) -------------------------------- */
 int dsx_io_read_chunks(dsx_ctx* ctx, const char* const* paths, void* const* dst, const size_t* bytes, int n,
-                       int threads, int zlib_chunks, uint16_t fill_value) {
+                       int threads, int codec, uint16_t fill_value) {
   if (n < 0 || (n > 0 && (!paths || !dst || !bytes))) return DSX_EINVAL;
-  const std::string e = dsx::io_read_chunks(paths, dst, bytes, n, threads, zlib_chunks != 0, fill_value);
+  if (codec < DSX_CODEC_RAW || codec > DSX_CODEC_BLOSC) return fail(ctx, DSX_EINVAL, "unknown chunk codec");
+  const std::string e = dsx::io_read_chunks(paths, dst, bytes, n, threads, codec, fill_value);
   if (!e.empty()) return fail(ctx, DSX_EIO, e);
   return DSX_OK;
 }
@@ -1463,6 +1464,33 @@ int dsx_io_write_chunks(dsx_ctx* ctx, const char* const* paths, const void* cons
   if (n < 0 || (n > 0 && (!paths || !src || !bytes))) return DSX_EINVAL;
   const std::string e = dsx::io_write_chunks(paths, src, bytes, n, threads, zlib_level);
   if (!e.empty()) return fail(ctx, DSX_EIO, e);
+  return DSX_OK;
+}
+
+int dsx_io_write_chunks_blosc(dsx_ctx* ctx, const char* const* paths, const void* const* src, const size_t* bytes,
+                              int n, int threads, int clevel, int typesize, int shuffle) {
+  if (n < 0 || (n > 0 && (!paths || !src || !bytes))) return DSX_EINVAL;
+  if (typesize < 1 || typesize > 255 || clevel < 0 || clevel > 9) return fail(ctx, DSX_EINVAL, "bad Blosc parameters");
+  const std::string e = dsx::io_write_chunks(paths, src, bytes, n, threads, clevel, typesize, shuffle != 0);
+  if (!e.empty()) return fail(ctx, DSX_EIO, e);
+  return DSX_OK;
+}
+int dsx_blosc_decode(const void* frame, size_t frame_bytes, void* dst, size_t dst_bytes) {
+  if (!frame || (!dst && dst_bytes)) return DSX_EINVAL;
+  const std::string e = dsx::blosc_decode((const unsigned char*)frame, frame_bytes, dst, dst_bytes);
+  if (!e.empty()) return fail(nullptr, DSX_EIO, e);
+  return DSX_OK;
+}
+int dsx_blosc_encode(const void* src, size_t bytes, int typesize, int clevel, int shuffle, void* frame,
+                     size_t frame_capacity, size_t* frame_bytes) {
+  if ((!src && bytes) || !frame || !frame_bytes) return DSX_EINVAL;
+  if (typesize < 1 || typesize > 255 || clevel < 0 || clevel > 9) return fail(nullptr, DSX_EINVAL, "bad Blosc parameters");
+  std::vector<unsigned char> out;
+  const std::string e = dsx::blosc_encode(src, bytes, typesize, clevel, shuffle != 0, out);
+  if (!e.empty()) return fail(nullptr, DSX_EIO, e);
+  if (out.size() > frame_capacity) return fail(nullptr, DSX_EINVAL, "frame buffer too small (bytes + 16 always fits)");
+  memcpy(frame, out.data(), out.size());
+  *frame_bytes = out.size();
   return DSX_OK;
 }
 

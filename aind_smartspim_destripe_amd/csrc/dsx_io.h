@@ -4,12 +4,21 @@
 // (zarr_destriper.py:1138-1172; zarr + numcodecs do the file work).  Once the filter runs at tens of
 // thousands of planes per second the Python interpreter cannot even open the chunk files fast enough
 // (1024 files of 2 MiB per 64-plane block), so this part is native: a static partition of the chunk list
-// over std::threads, raw or zlib chunks (Blosc is not available offline), whole-file reads straight into
-// the destination, writes to a temporary name + rename (a reader sees a chunk whole or not at all).
+// over std::threads, raw, zlib or Blosc chunks, whole-file reads straight into the destination, writes to a
+// temporary name + rename (a reader sees a chunk whole or not at all).
+//
+// Blosc (the production codec: numcodecs.Blosc(cname="zstd", clevel=3, shuffle=SHUFFLE), zarr_destriper.py:1066-1074)
+// is the third-party c-blosc 1.x container; neither it nor numcodecs is installed here, but the image carries
+// libzstd.so.1 (and liblz4.so.1), so the container is restated from its published format (c-blosc README_HEADER.rst
+// / blosc.c: 16-byte header, block start table, per-block streams with an int32 length each, byte shuffle) and the
+// inner codecs are dlopen'ed.  PARITY UNPINNED: no file written by the real library exists in the reference or in
+// this image to check against -- tests cover round trips, hand-assembled frames (tests/test_formats.py builds them
+// in pure Python from the format description, incl. split blocks this writer never emits) and malformed input.
 // Pure C++ (no HIP): tests/host can build it with g++.
 #ifndef DSX_IO_H
 #define DSX_IO_H
 
+#include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <stdint.h>
@@ -18,6 +27,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -91,12 +101,192 @@ inline std::string io_parallel(int n, int threads, F&& one) {
   return err;
 }
 
-// n chunk files -> dst[i] (bytes[i] each, decompressed size).  zlib_chunks: the files are zlib streams.
+// ---- Blosc 1 container ---------------------------------------------------------------------------------------
+constexpr int kCodecRaw = 0, kCodecZlib = 1, kCodecBlosc = 2;  // DSX_CODEC_* of include/dsx.h
+constexpr int kBloscHeader = 16, kBloscMinBuffer = 128, kBloscMaxSplits = 16;
+constexpr unsigned kBloscShuffle = 0x1, kBloscMemcpyed = 0x2, kBloscBitshuffle = 0x4, kBloscDontSplit = 0x10;
+enum BloscInner { kInnerBlosclz = 0, kInnerLz4 = 1, kInnerSnappy = 2, kInnerZlib = 3, kInnerZstd = 4 };
+
+struct InnerCodecs {
+  // libzstd.so.1
+  size_t (*zstd_compress)(void*, size_t, const void*, size_t, int) = nullptr;
+  size_t (*zstd_decompress)(void*, size_t, const void*, size_t) = nullptr;
+  size_t (*zstd_bound)(size_t) = nullptr;
+  unsigned (*zstd_is_error)(size_t) = nullptr;
+  // liblz4.so.1
+  int (*lz4_decompress_safe)(const char*, char*, int, int) = nullptr;
+};
+inline const InnerCodecs& inner_codecs() {
+  static InnerCodecs c;
+  static std::once_flag once;
+  std::call_once(once, []() {
+    for (const char* name : {"libzstd.so.1", "libzstd.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+        c.zstd_compress = (decltype(c.zstd_compress))dlsym(h, "ZSTD_compress");
+        c.zstd_decompress = (decltype(c.zstd_decompress))dlsym(h, "ZSTD_decompress");
+        c.zstd_bound = (decltype(c.zstd_bound))dlsym(h, "ZSTD_compressBound");
+        c.zstd_is_error = (decltype(c.zstd_is_error))dlsym(h, "ZSTD_isError");
+        break;
+      }
+    }
+    for (const char* name : {"liblz4.so.1", "liblz4.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+        c.lz4_decompress_safe = (decltype(c.lz4_decompress_safe))dlsym(h, "LZ4_decompress_safe");
+        break;
+      }
+    }
+  });
+  return c;
+}
+inline bool zstd_available() {
+  const InnerCodecs& c = inner_codecs();
+  return c.zstd_compress && c.zstd_decompress && c.zstd_bound && c.zstd_is_error;
+}
+
+inline uint32_t le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline void put_le32(unsigned char* p, uint32_t v) { p[0] = v & 255; p[1] = (v >> 8) & 255; p[2] = (v >> 16) & 255; p[3] = v >> 24; }
+
+// byte shuffle of one block: element i, byte j -> position j * nelem + i; the (blocksize % typesize) tail is copied
+inline void blosc_shuffle(size_t typesize, size_t blocksize, const unsigned char* src, unsigned char* dst) {
+  const size_t ne = blocksize / typesize;
+  for (size_t j = 0; j < typesize; ++j)
+    for (size_t i = 0; i < ne; ++i) dst[j * ne + i] = src[i * typesize + j];
+  memcpy(dst + ne * typesize, src + ne * typesize, blocksize - ne * typesize);
+}
+inline void blosc_unshuffle(size_t typesize, size_t blocksize, const unsigned char* src, unsigned char* dst) {
+  const size_t ne = blocksize / typesize;
+  if (typesize == 2) {  // the production dtype: two sequential source streams, interleaved stores
+    const unsigned char* lo = src;
+    const unsigned char* hi = src + ne;
+    for (size_t i = 0; i < ne; ++i) { dst[2 * i] = lo[i]; dst[2 * i + 1] = hi[i]; }
+  } else {
+    for (size_t j = 0; j < typesize; ++j)
+      for (size_t i = 0; i < ne; ++i) dst[i * typesize + j] = src[j * ne + i];
+  }
+  memcpy(dst + ne * typesize, src + ne * typesize, blocksize - ne * typesize);
+}
+
+// One Blosc frame -> dst (exactly `want` bytes).  Returns "" or an error text.
+inline std::string blosc_decode(const unsigned char* src, size_t n, void* dst, size_t want) {
+  if (n < (size_t)kBloscHeader) return "blosc: frame shorter than its header";
+  const unsigned version = src[0], flags = src[2], typesize = src[3] ? src[3] : 1;
+  const size_t nbytes = le32(src + 4), blocksize = le32(src + 8), cbytes = le32(src + 12);
+  if (version < 1 || version > 2) return "blosc: unknown format version " + std::to_string(version);
+  if (nbytes != want) return "blosc: frame holds " + std::to_string(nbytes) + " bytes, chunk needs " + std::to_string(want);
+  if (cbytes > n || cbytes < (size_t)kBloscHeader) return "blosc: compressed size field does not fit the file";
+  if (nbytes == 0) return "";
+  if (flags & kBloscMemcpyed) {
+    if (cbytes < kBloscHeader + nbytes) return "blosc: truncated stored frame";
+    memcpy(dst, src + kBloscHeader, nbytes);
+    return "";
+  }
+  if (flags & kBloscBitshuffle) return "blosc: bit-shuffled frames are not supported";
+  if (blocksize == 0 || blocksize > nbytes) return "blosc: bad block size";
+  const size_t nblocks = (nbytes + blocksize - 1) / blocksize;
+  if (kBloscHeader + 4 * nblocks > cbytes) return "blosc: truncated block table";
+  const int inner = (flags >> 5) & 7;
+  const InnerCodecs& lib = inner_codecs();
+  if (inner == kInnerZstd && !zstd_available()) return "blosc: libzstd.so.1 is not available";
+  if (inner == kInnerLz4 && !lib.lz4_decompress_safe) return "blosc: liblz4.so.1 is not available";
+  if (inner == kInnerBlosclz || inner == kInnerSnappy || inner > kInnerZstd)
+    return std::string("blosc: inner codec ") + (inner == kInnerBlosclz ? "blosclz" : inner == kInnerSnappy ? "snappy" : "?") +
+           " is not supported (zstd, lz4, zlib are)";
+  const bool shuffle = (flags & kBloscShuffle) && typesize > 1;
+  const bool dont_split = (flags & kBloscDontSplit) != 0;
+  std::vector<unsigned char> tmp(shuffle ? blocksize : 0);
+  for (size_t b = 0; b < nblocks; ++b) {
+    const size_t bsize = (b + 1 == nblocks) ? nbytes - b * blocksize : blocksize;
+    const bool leftover = bsize != blocksize;
+    const size_t nsplits = (!dont_split && !leftover && typesize <= (unsigned)kBloscMaxSplits &&
+                            blocksize / typesize >= (size_t)kBloscMinBuffer) ? typesize : 1;
+    const size_t neblock = bsize / nsplits;
+    size_t pos = le32(src + kBloscHeader + 4 * b);
+    unsigned char* out = shuffle ? tmp.data() : (unsigned char*)dst + b * blocksize;
+    for (size_t j = 0; j < nsplits; ++j) {
+      if (pos + 4 > cbytes) return "blosc: block stream outside the frame";
+      const size_t cs = le32(src + pos);
+      pos += 4;
+      if (cs > cbytes - pos) return "blosc: block stream outside the frame";
+      if (cs == neblock) {
+        memcpy(out, src + pos, neblock);
+      } else if (inner == kInnerZstd) {
+        const size_t r = lib.zstd_decompress(out, neblock, src + pos, cs);
+        if (lib.zstd_is_error(r) || r != neblock) return "blosc: bad zstd stream";
+      } else if (inner == kInnerLz4) {
+        if (lib.lz4_decompress_safe((const char*)src + pos, (char*)out, (int)cs, (int)neblock) != (int)neblock)
+          return "blosc: bad lz4 stream";
+      } else {
+        uLongf got = (uLongf)neblock;
+        if (uncompress(out, &got, src + pos, (uLong)cs) != Z_OK || got != neblock) return "blosc: bad zlib stream";
+      }
+      pos += cs;
+      out += neblock;
+    }
+    if (shuffle) blosc_unshuffle(typesize, bsize, tmp.data(), (unsigned char*)dst + b * blocksize);
+  }
+  return "";
+}
+
+// src -> one Blosc frame with zstd inside (what numcodecs.Blosc(cname="zstd", clevel, shuffle) produces is one of many
+// valid encodings; this writer emits unsplit blocks of 256 KiB and sets the "don't split" flag, which every c-blosc
+// >= 1.11 reader honours).  An incompressible buffer is stored (memcpyed frame) like c-blosc does.
+inline std::string blosc_encode(const void* src_, size_t n, int typesize, int clevel, bool shuffle,
+                                std::vector<unsigned char>& out) {
+  if (n > 0x7FFFFFEFu) return "blosc: buffer larger than a frame can hold";
+  if (typesize < 1 || typesize > 255) return "blosc: bad type size";
+  const unsigned char* src = (const unsigned char*)src_;
+  auto stored = [&]() {
+    out.resize(kBloscHeader + n);
+    memcpy(out.data() + kBloscHeader, src, n);
+    out[0] = 2; out[1] = 1; out[2] = (unsigned char)(kBloscMemcpyed | (shuffle && typesize > 1 ? kBloscShuffle : 0) |
+                                                     kBloscDontSplit | (kInnerZstd << 5));
+    out[3] = (unsigned char)typesize;
+    put_le32(out.data() + 4, (uint32_t)n);
+    put_le32(out.data() + 8, (uint32_t)n);
+    put_le32(out.data() + 12, (uint32_t)(kBloscHeader + n));
+    return std::string();
+  };
+  if (n < (size_t)kBloscMinBuffer || clevel <= 0) return stored();
+  if (!zstd_available()) return "blosc: libzstd.so.1 is not available";
+  const InnerCodecs& lib = inner_codecs();
+  size_t blocksize = std::min<size_t>(n, 256 * 1024);
+  if (blocksize > (size_t)typesize) blocksize -= blocksize % typesize;
+  const size_t nblocks = (n + blocksize - 1) / blocksize;
+  const bool do_shuffle = shuffle && typesize > 1;
+  const size_t bound = lib.zstd_bound(blocksize);
+  out.resize(kBloscHeader + 4 * nblocks);
+  std::vector<unsigned char> tmp(do_shuffle ? blocksize : 0), comp(bound);
+  // c-blosc maps its levels 1 ... 9 onto zstd's (clevel 9 -> 22, else 2 * clevel - 1): level 3 -> zstd 5
+  const int zlevel = clevel >= 9 ? 22 : 2 * clevel - 1;
+  for (size_t b = 0; b < nblocks; ++b) {
+    const size_t bsize = (b + 1 == nblocks) ? n - b * blocksize : blocksize;
+    const unsigned char* blk = src + b * blocksize;
+    if (do_shuffle) { blosc_shuffle((size_t)typesize, bsize, blk, tmp.data()); blk = tmp.data(); }
+    size_t cs = lib.zstd_compress(comp.data(), bound, blk, bsize, zlevel);
+    const bool raw = lib.zstd_is_error(cs) || cs >= bsize;  // a stream as long as the block means "stored" to a reader
+    if (raw) cs = bsize;
+    const size_t at = out.size();
+    if (at + 4 + cs >= kBloscHeader + n) return stored();  // not smaller than the data: store the whole buffer
+    put_le32(out.data() + kBloscHeader + 4 * b, (uint32_t)at);
+    out.resize(at + 4 + cs);
+    put_le32(out.data() + at, (uint32_t)cs);
+    memcpy(out.data() + at + 4, raw ? blk : comp.data(), cs);
+  }
+  out[0] = 2; out[1] = 1;
+  out[2] = (unsigned char)((do_shuffle ? kBloscShuffle : 0) | kBloscDontSplit | (kInnerZstd << 5));
+  out[3] = (unsigned char)typesize;
+  put_le32(out.data() + 4, (uint32_t)n);
+  put_le32(out.data() + 8, (uint32_t)blocksize);
+  put_le32(out.data() + 12, (uint32_t)out.size());
+  return "";
+}
+
+// n chunk files -> dst[i] (bytes[i] each, decompressed size).  codec: kCodecRaw / kCodecZlib / kCodecBlosc.
 // A missing chunk is filled with the 16-bit fill value (zarr semantics).
 inline std::string io_read_chunks(const char* const* paths, void* const* dst, const size_t* bytes, int n,
-                                  int threads, bool zlib_chunks, uint16_t fill) {
+                                  int threads, int codec, uint16_t fill) {
   return io_parallel(n, threads, [&](int i) -> std::string {
-    if (!zlib_chunks) {
+    if (codec == kCodecRaw) {
       const long long got = io_read_file(paths[i], dst[i], bytes[i]);
       if (got == -1) {
         uint16_t* p = (uint16_t*)dst[i];
@@ -116,6 +306,10 @@ inline std::string io_read_chunks(const char* const* paths, void* const* dst, co
     std::vector<unsigned char> raw((size_t)st.st_size);
     if (io_read_file(paths[i], raw.data(), raw.size()) != (long long)raw.size())
       return std::string("short or failed read of chunk ") + paths[i];
+    if (codec == kCodecBlosc) {
+      const std::string e = blosc_decode(raw.data(), raw.size(), dst[i], bytes[i]);
+      return e.empty() ? e : e + " (" + paths[i] + ")";
+    }
     uLongf out_len = (uLongf)bytes[i];
     if (uncompress((Bytef*)dst[i], &out_len, raw.data(), (uLong)raw.size()) != Z_OK || out_len != bytes[i])
       return std::string("zlib: bad chunk ") + paths[i];
@@ -123,10 +317,18 @@ inline std::string io_read_chunks(const char* const* paths, void* const* dst, co
   });
 }
 
-// src[i] (bytes[i]) -> chunk file paths[i]; zlib_level < 0: raw.
+// src[i] (bytes[i]) -> chunk file paths[i]; zlib_level < 0: raw; blosc_typesize > 0: Blosc-zstd frames of that element
+// size at compression level zlib_level with byte shuffle (blosc_shuffle_on) -- the production codec.
 inline std::string io_write_chunks(const char* const* paths, const void* const* src, const size_t* bytes, int n,
-                                   int threads, int zlib_level) {
+                                   int threads, int zlib_level, int blosc_typesize = 0, bool blosc_shuffle_on = true) {
   return io_parallel(n, threads, [&](int i) -> std::string {
+    if (blosc_typesize > 0) {
+      std::vector<unsigned char> frame;
+      const std::string e = blosc_encode(src[i], bytes[i], blosc_typesize, zlib_level, blosc_shuffle_on, frame);
+      if (!e.empty()) return e + " (" + paths[i] + ")";
+      if (!io_write_file_atomic(paths[i], frame.data(), frame.size())) return std::string("cannot write chunk ") + paths[i];
+      return "";
+    }
     if (zlib_level < 0) {
       if (!io_write_file_atomic(paths[i], src[i], bytes[i])) return std::string("cannot write chunk ") + paths[i];
       return "";

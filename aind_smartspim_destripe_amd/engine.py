@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "dsx_comm_unique_id", "dsx_comm_init", "dsx_comm_destroy", "dsx_comm_broadcast", "dsx_comm_allreduce_f64",
     "dsx_malloc_host", "dsx_free_host", "dsx_memcpy_h2d_async", "dsx_memcpy_d2h_async",
     "dsx_stream_wait", "dsx_stream_sync", "dsx_event_record", "dsx_event_sync",
-    "dsx_io_read_chunks", "dsx_io_write_chunks",
+    "dsx_io_read_chunks", "dsx_io_write_chunks", "dsx_io_write_chunks_blosc", "dsx_blosc_decode", "dsx_blosc_encode",
 ]  # fmt: skip
 
 
@@ -146,6 +146,11 @@ def load_library(path=None):
                                        ctypes.POINTER(ctypes.c_size_t), i32, i32, i32, ctypes.c_uint16]  # fmt: skip
     lib.dsx_io_write_chunks.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
                                         ctypes.POINTER(ctypes.c_size_t), i32, i32, i32]  # fmt: skip
+    lib.dsx_io_write_chunks_blosc.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
+                                              ctypes.POINTER(ctypes.c_size_t), i32, i32, i32, i32, i32]  # fmt: skip
+    lib.dsx_blosc_decode.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t]
+    lib.dsx_blosc_encode.argtypes = [vp, ctypes.c_size_t, i32, i32, i32, vp, ctypes.c_size_t,
+                                     ctypes.POINTER(ctypes.c_size_t)]  # fmt: skip
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("dsx_destroy", "dsx_last_error"):
@@ -431,21 +436,28 @@ class DestripeEngine:
         self._check(self._lib.dsx_stream_sync(self._ctx, int(stream)))
 
     # -- chunk files on native threads (dsx_io.h); ctypes releases the GIL for the call -----------
-    def io_read_chunks(self, paths, arrays, threads=16, zlib_chunks=False, fill_value=0):
-        """Chunk files ``paths[i]`` -> ``arrays[i]`` (C-contiguous NumPy arrays of the decompressed chunk size)."""
+    def io_read_chunks(self, paths, arrays, threads=16, zlib_chunks=False, fill_value=0, codec=None):
+        """Chunk files ``paths[i]`` -> ``arrays[i]`` (C-contiguous NumPy arrays of the decompressed chunk size).
+        ``codec``: ``DSX_CODEC_*`` (0 raw, 1 zlib, 2 Blosc); default from ``zlib_chunks``."""
         n = len(paths)
         cp = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
         dp = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
         nb = (ctypes.c_size_t * n)(*[a.nbytes for a in arrays])
-        self._check(self._lib.dsx_io_read_chunks(self._ctx, cp, dp, nb, n, int(threads), 1 if zlib_chunks else 0,
-                                                 int(fill_value)))  # fmt: skip
+        code = (1 if zlib_chunks else 0) if codec is None else int(codec)
+        self._check(self._lib.dsx_io_read_chunks(self._ctx, cp, dp, nb, n, int(threads), code, int(fill_value)))
 
-    def io_write_chunks(self, paths, arrays, threads=16, zlib_level=-1):
-        """``arrays[i]`` -> chunk files ``paths[i]`` (raw, or zlib streams for ``zlib_level >= 0``), atomically."""
+    def io_write_chunks(self, paths, arrays, threads=16, zlib_level=-1, blosc=None):
+        """``arrays[i]`` -> chunk files ``paths[i]`` (raw, zlib streams for ``zlib_level >= 0``, or Blosc-zstd frames for
+        ``blosc = (clevel, typesize, shuffle)``), atomically."""
         n = len(paths)
         cp = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
         dp = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
         nb = (ctypes.c_size_t * n)(*[a.nbytes for a in arrays])
+        if blosc is not None:
+            clevel, typesize, shuffle = blosc
+            self._check(self._lib.dsx_io_write_chunks_blosc(self._ctx, cp, dp, nb, n, int(threads), int(clevel),
+                                                            int(typesize), 1 if shuffle else 0))  # fmt: skip
+            return
         self._check(self._lib.dsx_io_write_chunks(self._ctx, cp, dp, nb, n, int(threads), int(zlib_level)))
 
     def event_record(self, slot, stream):

@@ -1,11 +1,13 @@
 """Minimal Zarr-v2 directory store (read / write) for the chunk map.
 
-Neither ``zarr`` nor ``numcodecs`` is installed in this environment (and blosc / zstd are not
-available offline), so the chunk map carries its own small implementation of the subset it needs:
-C-order arrays, little-endian numeric dtypes, ``compressor`` ``null`` or ``zlib``, ``"."`` or ``"/"``
-chunk-key separators, basic slicing with unit steps.  The reference's production arrays are
-``uint16``, chunks ``(1, 1, 64, 128, 128)``, Blosc-zstd, ``dimension_separator="/"``
-(``zarr_destriper.py:1066-1074``); Blosc chunks are rejected with a clear error.
+Neither ``zarr`` nor ``numcodecs`` is installed in this environment, so the chunk map carries its own small
+implementation of the subset it needs: C-order arrays, little-endian numeric dtypes, ``compressor`` ``null``,
+``zlib`` or ``blosc``, ``"."`` or ``"/"`` chunk-key separators, basic slicing with unit steps.  The reference's
+production arrays are ``uint16``, chunks ``(1, 1, 64, 128, 128)``, ``Blosc(cname="zstd", clevel=3, shuffle=SHUFFLE)``,
+``dimension_separator="/"`` (``zarr_destriper.py:1066-1074``).  Blosc frames are decoded / encoded by the native
+library (``csrc/dsx_io.h``: the c-blosc 1.x container restated from its format description, ``libzstd.so.1`` /
+``liblz4.so.1`` of the image ``dlopen``ed; frames with zstd, lz4 or zlib inside are read, zstd frames are written).
+Parity of that codec is UNPINNED: no file written by the real library exists here to check against.
 """
 
 import itertools
@@ -14,6 +16,43 @@ import os
 import zlib
 
 import numpy as np
+
+CODEC_RAW, CODEC_ZLIB, CODEC_BLOSC = 0, 1, 2  # DSX_CODEC_* of include/dsx.h
+# numcodecs.Blosc(cname="zstd", clevel=3, shuffle=Blosc.SHUFFLE).get_config(), zarr_destriper.py:1066-1074
+BLOSC_ZSTD = {"id": "blosc", "cname": "zstd", "clevel": 3, "shuffle": 1, "blocksize": 0}
+
+
+def _native():
+    from . import engine
+
+    return engine.load_library()
+
+
+def blosc_decode(frame, nbytes):
+    """One Blosc frame -> ``bytes`` object of ``nbytes`` (``dsx_blosc_decode``)."""
+    import ctypes
+
+    lib = _native()
+    out = ctypes.create_string_buffer(nbytes)
+    rc = lib.dsx_blosc_decode(frame, len(frame), out, nbytes)
+    if rc != 0:
+        raise ValueError((lib.dsx_last_error(None) or b"blosc: decode failed").decode())
+    return out.raw
+
+
+def blosc_encode(raw, typesize, clevel=3, shuffle=True):
+    """Bytes-like -> one Blosc frame with zstd inside (``dsx_blosc_encode``)."""
+    import ctypes
+
+    lib = _native()
+    raw = bytes(raw)
+    out = ctypes.create_string_buffer(len(raw) + 16)
+    n = ctypes.c_size_t()
+    rc = lib.dsx_blosc_encode(raw, len(raw), int(typesize), int(clevel), 1 if shuffle else 0, out, len(raw) + 16,
+                              ctypes.byref(n))  # fmt: skip
+    if rc != 0:
+        raise ValueError((lib.dsx_last_error(None) or b"blosc: encode failed").decode())
+    return out.raw[: n.value]
 
 
 class MiniZarrArray:
@@ -29,14 +68,47 @@ class MiniZarrArray:
             self.compressor = None
         elif comp.get("id") == "zlib":
             self.compressor = ("zlib", int(comp.get("level", 1)))
+        elif comp.get("id") == "blosc":
+            # reading only needs the frames (their headers name the inner codec); writing needs cname zstd
+            self.compressor = ("blosc", int(comp.get("clevel", 5)), str(comp.get("cname", "lz4")),
+                               int(comp.get("shuffle", 1)))  # fmt: skip
         else:
             raise NotImplementedError(
-                "compressor {!r} is not available offline (only null / zlib)".format(comp.get("id"))
+                "compressor {!r} is not available (null / zlib / blosc are)".format(comp.get("id"))
             )
         if meta.get("order", "C") != "C" or meta.get("filters"):
             raise NotImplementedError("only C-order arrays without filters are supported")
         self.ndim = len(self.shape)
         self._dirs_made = set()
+
+    @property
+    def codec(self):
+        """``DSX_CODEC_*`` of the chunk files (``dsx_io_read_chunks``)."""
+        return {None: CODEC_RAW, "zlib": CODEC_ZLIB, "blosc": CODEC_BLOSC}[self.compressor and self.compressor[0]]
+
+    def blosc_write_params(self):
+        """``(clevel, typesize, byte shuffle)`` for ``dsx_io_write_chunks_blosc``; raises for what the writer lacks."""
+        _, clevel, cname, shuffle = self.compressor
+        if cname != "zstd":
+            raise NotImplementedError("Blosc frames are written with zstd inside; cname {!r} is read-only".format(cname))
+        if shuffle == 2 or (shuffle == -1 and self.dtype.itemsize == 1):
+            raise NotImplementedError("Blosc bit-shuffle is not implemented")
+        return clevel, self.dtype.itemsize, shuffle != 0
+
+    def _decode(self, raw):
+        if self.compressor is None:
+            return raw
+        if self.compressor[0] == "zlib":
+            return zlib.decompress(raw)
+        return blosc_decode(raw, int(np.prod(self.chunks)) * self.dtype.itemsize)
+
+    def _encode(self, raw):
+        if self.compressor is None:
+            return raw
+        if self.compressor[0] == "zlib":
+            return zlib.compress(raw, self.compressor[1])
+        clevel, typesize, shuffle = self.blosc_write_params()
+        return blosc_encode(raw, typesize, clevel, shuffle)
 
     # -- construction -------------------------------------------------------------------------
     @classmethod
@@ -48,8 +120,12 @@ class MiniZarrArray:
         comp = None
         if compressor == "zlib":
             comp = {"id": "zlib", "level": 1}
+        elif compressor == "blosc":
+            comp = dict(BLOSC_ZSTD)
+        elif isinstance(compressor, dict):
+            comp = dict(compressor)  # a numcodecs get_config() dict
         elif compressor is not None:
-            raise NotImplementedError("only null / zlib compressors")
+            raise NotImplementedError("compressors: None, 'zlib', 'blosc' or a numcodecs config dict")
         meta = {
             "zarr_format": 2,
             "shape": list(shape),
@@ -88,9 +164,7 @@ class MiniZarrArray:
         if not os.path.exists(p):
             return np.full(self.chunks, self.fill_value, dtype=self.dtype)
         with open(p, "rb") as f:
-            raw = f.read()
-        if self.compressor is not None:
-            raw = zlib.decompress(raw)
+            raw = self._decode(f.read())
         return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks).copy()
 
     def read_chunk_into(self, idx, out_flat):
@@ -109,7 +183,7 @@ class MiniZarrArray:
                 if got != len(view):
                     raise ValueError("chunk {} has {} bytes, expected {}".format(p, got, len(view)))
                 return
-            raw = zlib.decompress(f.read())
+            raw = self._decode(f.read())
         out_flat[...] = np.frombuffer(raw, dtype=self.dtype)
 
     def write_chunk_flat(self, idx, flat):
@@ -123,8 +197,7 @@ class MiniZarrArray:
             os.makedirs(d, exist_ok=True)
             self._dirs_made.add(d)
         raw = memoryview(np.ascontiguousarray(block, dtype=self.dtype)).cast("B")
-        if self.compressor is not None:
-            raw = zlib.compress(raw, self.compressor[1])
+        raw = self._encode(raw)
         with open(p + ".tmp", "wb", buffering=0) as f:
             f.write(raw)
         os.replace(p + ".tmp", p)

@@ -300,7 +300,7 @@ class _DeviceBlocks:
         stage = self.stage_in[k]
         self.eng.io_read_chunks([self.src._chunk_path(lead + (bz0 + i[0], i[1], i[2])) for i in idx],
                                 [stage[i] for i in idx], threads=self.io_threads,
-                                zlib_chunks=self.src.compressor is not None, fill_value=int(self.src.fill_value))  # fmt: skip
+                                codec=self.src.codec, fill_value=int(self.src.fill_value))  # fmt: skip
         self.timing["read_s"] += time.perf_counter() - t0
         return nbz, zoff
 
@@ -312,9 +312,11 @@ class _DeviceBlocks:
         oz0 = z0 // self.co[0]
         out = self.stage_out[k]
         odx = list(itertools.product(range(nbo), range(self.go[1]), range(self.go[2])))
-        level = -1 if self.dst.compressor is None else int(self.dst.compressor[1])
+        comp = self.dst.compressor
+        level = -1 if comp is None else int(comp[1])
         self.eng.io_write_chunks([self.dst._chunk_path(lead + (oz0 + i[0], i[1], i[2])) for i in odx],
-                                 [out[i] for i in odx], threads=self.io_threads, zlib_level=level)
+                                 [out[i] for i in odx], threads=self.io_threads, zlib_level=level,
+                                 blosc=self.dst.blosc_write_params() if comp and comp[0] == "blosc" else None)  # fmt: skip
         self.timing["write_s"] += time.perf_counter() - t0
 
     # -- device stage (asynchronous) -----------------------------------------------------------

@@ -178,14 +178,29 @@ int dsx_downsample2_u16(dsx_ctx* ctx, const void* d_src, void* d_dst, int Z, int
 
 /* Host side of the chunk map: n Zarr chunk files <-> memory (normally the pinned staging buffers) on
  * `threads` native threads -- what zarr / numcodecs do under the reference's worker processes
- * (zarr_destriper.py:336, 1042-1074).  Raw chunks or zlib streams (zlib_chunks / zlib_level >= 0);
- * a missing chunk reads as the 16-bit fill value; writes go to "<path>.tmp" and are renamed.
- * bytes[i] is the decompressed chunk size.  Synchronous; no GPU involved (ctx may be NULL: the
- * message of a failure is then read with dsx_last_error(NULL)).                                   */
+ * (zarr_destriper.py:336, 1042-1074).  codec: raw chunks, zlib streams, or Blosc frames -- the production
+ * arrays are Blosc(cname="zstd", clevel=3, shuffle=SHUFFLE) (zarr_destriper.py:1066-1074); the c-blosc 1.x
+ * container is restated in csrc/dsx_io.h (zstd / lz4 / zlib inside, byte shuffle; libzstd.so.1 is dlopen'ed),
+ * parity unpinned: no file of the real library is available to check against.  A missing chunk reads as the
+ * 16-bit fill value; writes go to "<path>.tmp" and are renamed.  bytes[i] is the decompressed chunk size.
+ * Synchronous; no GPU involved (ctx may be NULL: the message of a failure is then read with
+ * dsx_last_error(NULL)).                                                                              */
+#define DSX_CODEC_RAW 0
+#define DSX_CODEC_ZLIB 1
+#define DSX_CODEC_BLOSC 2
 int dsx_io_read_chunks(dsx_ctx* ctx, const char* const* paths, void* const* dst, const size_t* bytes,
-                       int n, int threads, int zlib_chunks, uint16_t fill_value);
+                       int n, int threads, int codec, uint16_t fill_value);
+/* zlib_level < 0: raw chunks, otherwise zlib streams of that level */
 int dsx_io_write_chunks(dsx_ctx* ctx, const char* const* paths, const void* const* src,
                         const size_t* bytes, int n, int threads, int zlib_level);
+/* Blosc frames with zstd inside: clevel 0 ... 9 (Blosc's scale), typesize = element size, shuffle 0 / 1 */
+int dsx_io_write_chunks_blosc(dsx_ctx* ctx, const char* const* paths, const void* const* src,
+                              const size_t* bytes, int n, int threads, int clevel, int typesize, int shuffle);
+/* One frame in memory (what numcodecs.Blosc.decode / .encode do for one chunk); errors: dsx_last_error(NULL).
+ * A frame never exceeds bytes + 16.                                                                    */
+int dsx_blosc_decode(const void* frame, size_t frame_bytes, void* dst, size_t dst_bytes);
+int dsx_blosc_encode(const void* src, size_t bytes, int typesize, int clevel, int shuffle, void* frame,
+                     size_t frame_capacity, size_t* frame_bytes);
 
 /* flatfield_correction() of one plane as a stand-alone call (filtering.py:338-414): dark subtraction
  * (integer planes truncate, :400-403), division by the flat, baseline, clip, uint16.  dark is
