@@ -340,7 +340,12 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   // their histograms (and, below, their row filters) run on the part's helper stream BESIDE the coarse
   // levels' launches instead of after them.
   const bool split = v.helper != nullptr && fuse12 && L >= 3;
+  // DSX_SKIP_HIST / DSX_SKIP_ROW: bit masks of level indices whose histogram / row-filter launch is left out
+  // (diagnosis only, results are wrong): what the chain would gain if that kernel were free
+  static const int skip_hist = getenv("DSX_SKIP_HIST") ? atoi(getenv("DSX_SKIP_HIST")) : 0;
+  static const int skip_row = getenv("DSX_SKIP_ROW") ? atoi(getenv("DSX_SKIP_ROW")) : 0;
   auto hist_level = [&](int l, hipStream_t hs) -> int {
+    if ((skip_hist >> l) & 1) return DSX_OK;
     const dsx::LevelPlan& lp = p.lv[l];
     dsx::HistArgs a;
     a.ws = v.ws;
@@ -485,6 +490,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   }
   for (int l = 0; l < L && l < skip_from; ++l) {
     hipStream_t rs = (split_inv && l < 2) ? v.helper : s;
+    if ((skip_row >> l) & 1) continue;
     const dsx::LevelPlan& lp = p.lv[l];
     dsx::RowArgs a;
     memset(&a, 0, sizeof(a));

@@ -487,7 +487,9 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   const bool c_v0 = FUSE && (!EDGE || (jl >= 0 && jl < a.w)), c_v1 = FUSE && (!EDGE || (jl + 1 >= 0 && jl + 1 < a.w));
   const bool c_s0 = FUSE && out_lane && jl >= fg.own1_lo && jl < fg.own1_hi;
   const bool c_s1 = EDGE ? (FUSE && out_lane && jl + 1 >= fg.own1_lo && jl + 1 < fg.own1_hi) : c_s0;
-  const unsigned off_da = (unsigned)max(jl, 0) * 4u;
+  // DSX_ABLATE bit 64 (diagnosis, wrong results): every strip's da_1 row piece starts on a 512-byte boundary of the
+  // row -- what the store path would gain from aligned strip boundaries (they sit at multiples of 488 bytes)
+  const unsigned off_da = (unsigned)max(jl, 0) * 4u + ((FUSE && (a.ablate & 64)) ? 24u * (unsigned)strip : 0u);
   const int jo2 = fg.o2 + lane;                              // level-2 column of this lane
   const bool l2_valid = FUSE && lane < kFuseOut && (!EDGE || jo2 < a.w2);
   const bool l2_store = l2_valid && jo2 >= fg.own2_lo;
