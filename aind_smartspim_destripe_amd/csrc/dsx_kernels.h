@@ -542,7 +542,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     const float q = v.y * v.y;
     q2min = fminf(q2min, l2_valid ? q : __builtin_huge_valf());
     q2max = fmaxf(q2max, l2_valid ? q : 0.f);
-    if (l2_store && !(a.ablate & 16)) {
+    if (l2_store && !(a.ablate & (16 | 128))) {  // 128: diagnosis, only the level-2 stores are left out
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rs_aa2, off_2, (unsigned)(i2 * a.lda2) * 4u, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rs_da2, off_2, (unsigned)(i2 * a.ld2) * 4u, 0);
       if (l2_edge) {  // extension margins of aa_2, read by the next level's aligned vector loads
@@ -637,7 +637,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
       if (out_lane) {
         const int j = jl;
         const float q0 = res[1][0] * res[1][0], q1 = res[1][1] * res[1][1];
-        if (own_row && !(a.ablate & 16)) {  // da_1: owned rows and columns only (overlap rows / columns belong to a neighbour)
+        if (own_row && !(a.ablate & (16 | 256))) {  // (256: diagnosis, only the da_1 stores are left out)  da_1: owned rows and columns only (overlap rows / columns belong to a neighbour)
           const unsigned soff = (unsigned)(i * a.ld) * 4u;
           constexpr int aux = DSX_NT ? kBufNT : 0;
           if (c_s0 && c_s1) {
