@@ -638,7 +638,8 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
         const int j = jl;
         const float q0 = res[1][0] * res[1][0], q1 = res[1][1] * res[1][1];
         if (own_row && !(a.ablate & (16 | 256))) {  // (256: diagnosis, only the da_1 stores are left out)  da_1: owned rows and columns only (overlap rows / columns belong to a neighbour)
-          const unsigned soff = (unsigned)(i * a.ld) * 4u;
+          // (64: diagnosis, with the 512-byte strip pieces above: a row pitch of 33 cache lines -- no partial line at all)
+          const unsigned soff = (a.ablate & 64) ? (unsigned)i * 4224u : (unsigned)(i * a.ld) * 4u;
           constexpr int aux = DSX_NT ? kBufNT : 0;
           if (c_s0 && c_s1) {
             const dsx_u32x2 dv = {__float_as_uint(res[1][0]), __float_as_uint(res[1][1])};
