@@ -1500,6 +1500,13 @@ int dsx_blosc_encode(const void* src, size_t bytes, int typesize, int clevel, in
   return DSX_OK;
 }
 
+int dsx_png_unfilter(void* rows, int height, int stride, int bytes_per_pixel) {
+  if (!rows && height > 0) return DSX_EINVAL;
+  const std::string e = dsx::png_unfilter((unsigned char*)rows, height, stride, bytes_per_pixel);
+  if (!e.empty()) return fail(nullptr, DSX_EIO, e);
+  return DSX_OK;
+}
+
 /* ---- debug hooks ---------------------------------------------------------------------------- */
 int dsx_set_stop_after(dsx_ctx* ctx, int stage) {
   if (!ctx || stage < 0 || stage > 2) return DSX_EINVAL;

@@ -22,6 +22,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -278,6 +279,42 @@ inline std::string blosc_encode(const void* src_, size_t n, int typesize, int cl
   put_le32(out.data() + 4, (uint32_t)n);
   put_le32(out.data() + 8, (uint32_t)blocksize);
   put_le32(out.data() + 12, (uint32_t)out.size());
+  return "";
+}
+
+// PNG scanline reconstruction (ISO/IEC 15948 section 9): rows of 1 filter-type byte + `stride` bytes, in place.
+// Sub / Average / Paeth depend on the reconstructed byte `bpp` positions to the left: sequential, hence native.
+inline std::string png_unfilter(unsigned char* data, int height, int stride, int bpp) {
+  if (height < 0 || stride < 0 || bpp < 1) return "png: bad geometry";
+  const size_t pitch = (size_t)stride + 1;
+  for (int y = 0; y < height; ++y) {
+    unsigned char* cur = data + y * pitch + 1;
+    const unsigned char* up = y ? cur - pitch : nullptr;
+    const int type = cur[-1];
+    switch (type) {
+      case 0: break;
+      case 1:
+        for (int x = bpp; x < stride; ++x) cur[x] = (unsigned char)(cur[x] + cur[x - bpp]);
+        break;
+      case 2:
+        if (up) for (int x = 0; x < stride; ++x) cur[x] = (unsigned char)(cur[x] + up[x]);
+        break;
+      case 3:
+        for (int x = 0; x < stride; ++x) {
+          const int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0;
+          cur[x] = (unsigned char)(cur[x] + ((a + b) >> 1));
+        }
+        break;
+      case 4:
+        for (int x = 0; x < stride; ++x) {
+          const int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+          const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+          cur[x] = (unsigned char)(cur[x] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
+        }
+        break;
+      default: return "png: unknown filter type " + std::to_string(type) + " in row " + std::to_string(y);
+    }
+  }
   return "";
 }
 

@@ -21,7 +21,7 @@ from typing import Optional
 import numpy as np
 
 from . import filtering as fl
-from . import mini_tiff
+from . import mini_png, mini_tiff
 from .readers import SUPPORTED_READING_EXTENSIONS, PathLike, imread
 
 logger = logging.getLogger(__name__)
@@ -43,8 +43,8 @@ def _write_plane(filename, img, compression):
     ext = Path(filename).suffix
     if ext in (".tif", ".tiff"):
         mini_tiff.imwrite(filename, img)
-    elif ext == ".png":
-        raise NotImplementedError("PNG needs imageio, which is not available in this environment")
+    elif ext == ".png":  # iio.v3.imwrite(filename, img, compress_level=compression), destriper.py:107-110
+        mini_png.imwrite(filename, img, compress_level=compression)
     else:  # pragma: no cover - callers only pass supported extensions
         raise NotImplementedError(ext)
 

@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "dsx_malloc_host", "dsx_free_host", "dsx_memcpy_h2d_async", "dsx_memcpy_d2h_async",
     "dsx_stream_wait", "dsx_stream_sync", "dsx_event_record", "dsx_event_sync",
     "dsx_io_read_chunks", "dsx_io_write_chunks", "dsx_io_write_chunks_blosc", "dsx_blosc_decode", "dsx_blosc_encode",
+    "dsx_png_unfilter",
 ]  # fmt: skip
 
 
@@ -148,6 +149,7 @@ def load_library(path=None):
                                         ctypes.POINTER(ctypes.c_size_t), i32, i32, i32]  # fmt: skip
     lib.dsx_io_write_chunks_blosc.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
                                               ctypes.POINTER(ctypes.c_size_t), i32, i32, i32, i32, i32]  # fmt: skip
+    lib.dsx_png_unfilter.argtypes = [vp, i32, i32, i32]
     lib.dsx_blosc_decode.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t]
     lib.dsx_blosc_encode.argtypes = [vp, ctypes.c_size_t, i32, i32, i32, vp, ctypes.c_size_t,
                                      ctypes.POINTER(ctypes.c_size_t)]  # fmt: skip

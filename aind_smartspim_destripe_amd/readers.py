@@ -2,8 +2,7 @@
 
 ``SUPPORTED_READING_EXTENSIONS``, ``_get_extension`` (reference ``readers.py:16-31``), ``raw_imread``
 (``:34-63``) and ``imread`` (``:66-92``) keep their names, arguments and results.  ``tifffile`` and ``imageio`` are
-not installed here: TIFF goes through :mod:`mini_tiff`; PNG (``imageio``, ``readers.py:87-88``) is not available
-offline and raises ``NotImplementedError`` (SmartSPIM acquisitions are TIFF).
+not installed here: TIFF goes through :mod:`mini_tiff`, PNG (``imageio``, ``readers.py:86-87``) through :mod:`mini_png`.
 """
 
 import os
@@ -12,7 +11,7 @@ from typing import Union
 
 import numpy as np
 
-from . import mini_tiff
+from . import mini_png, mini_tiff
 
 PathLike = Union[os.PathLike, str]
 
@@ -54,13 +53,9 @@ def raw_imread(path):
         raise
 
 
-def _png_imread(path):
-    raise NotImplementedError("PNG needs imageio, which is not available in this environment")
-
-
 def imread(path: PathLike) -> np.array:
-    """Plane of a ``.tif`` / ``.tiff`` / ``.raw`` file; ``None`` for any other extension, like the reference."""
+    """Plane of a ``.tif`` / ``.tiff`` / ``.raw`` / ``.png`` file; ``None`` for any other extension, like the reference."""
     path = os.fspath(path)
-    loaders = {".raw": raw_imread, ".tif": mini_tiff.imread, ".tiff": mini_tiff.imread, ".png": _png_imread}
+    loaders = {".raw": raw_imread, ".tif": mini_tiff.imread, ".tiff": mini_tiff.imread, ".png": mini_png.imread}
     loader = loaders.get(_get_extension(path))
     return None if loader is None else loader(path)

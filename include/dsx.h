@@ -202,6 +202,10 @@ int dsx_blosc_decode(const void* frame, size_t frame_bytes, void* dst, size_t ds
 int dsx_blosc_encode(const void* src, size_t bytes, int typesize, int clevel, int shuffle, void* frame,
                      size_t frame_capacity, size_t* frame_bytes);
 
+/* PNG scanline reconstruction for the directory mode's reader (imageio's iio.imread, readers.py:86-87): `height`
+ * rows of one filter-type byte + `stride` bytes, un-filtered in place (Sub / Up / Average / Paeth).  Host only.  */
+int dsx_png_unfilter(void* rows, int height, int stride, int bytes_per_pixel);
+
 /* flatfield_correction() of one plane as a stand-alone call (filtering.py:338-414): dark subtraction
  * (integer planes truncate, :400-403), division by the flat, baseline, clip, uint16.  dark is
  * [dark_h][dark_w] >= the plane and is cropped to it (:377).  Device pointers, asynchronous.   */
