@@ -85,6 +85,10 @@ struct dsx_ctx {
   bool wl_set = false;
   float wl[4][dsx::kMaxTaps] = {};       // dec_lo, dec_hi, rec_lo, rec_hi of the current plan
   float wl_bank[4][dsx::kMaxTaps] = {};  // ... of the last dsx_set_wavelet
+  // DSX_FUSE_HIST: bit mask of level indices whose histogram / Otsu step runs inside the row filter (k_rowfilter<...,
+  // HIST>).  OFF by default: bit-identical results, but the plane barrier costs more than the saved pass over cH
+  // (single stream 6.2 instead of 5.1 ms per 256 planes; four streams of 64 planes stall)
+  int fuse_hist = 0;
   int ablate = 0;  // DSX_ABLATE environment variable: row-filter phase ablation, diagnosis only
   // sub-cohort streams: a cohort is split into parts that run their launch chains concurrently, so that
   // latency-bound (march) and compute-bound (row filter) kernels of different parts overlap on the chip
@@ -233,26 +237,39 @@ int rowfilter_waves_per_block(int M) {
   return best_w;
 }
 
-template <int CPL, int GF = -1, int NT = -1, int HALO = -1, int PLAN = 0>
-hipError_t launch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s) {
+template <int CPL, int GF = -1, int NT = -1, int HALO = -1, int PLAN = 0, bool HIST = false>
+hipError_t launch_rowfilter(const dsx::RowArgs& a_in, int npairs, int nb, hipStream_t s) {
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_set[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)dsx::k_rowfilter<CPL, GF, NT, HALO, PLAN>,
+    hipError_t e = hipFuncSetAttribute((const void*)dsx::k_rowfilter<CPL, GF, NT, HALO, PLAN, HIST>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev & 63] = true;
   }
   static const int force_wpb = getenv("DSX_ROW_WPB") ? atoi(getenv("DSX_ROW_WPB")) : 0;
-  const int wpb = force_wpb ? force_wpb : ((CPL > 18) ? 4 : rowfilter_waves_per_block(a.M));
-  const size_t smem = (size_t)a.M * (wpb + 1) * sizeof(float2);
-  dim3 grid((npairs + wpb - 1) / wpb, nb);
-  hipLaunchKernelGGL((dsx::k_rowfilter<CPL, GF, NT, HALO, PLAN>), grid, dim3(64 * wpb), smem, s, a);
+  const int wpb = force_wpb ? force_wpb : ((CPL > 18) ? 4 : rowfilter_waves_per_block(a_in.M));
+  const size_t smem = (size_t)a_in.M * (wpb + 1) * sizeof(float2);
+  dsx::RowArgs a = a_in;
+  a.blocks_per_plane = (npairs + wpb - 1) / wpb;  // HIST: work items are handed out by ticket, plane by plane
+  dim3 grid(a.blocks_per_plane, nb);
+  hipLaunchKernelGGL((dsx::k_rowfilter<CPL, GF, NT, HALO, PLAN, HIST>), grid, dim3(64 * wpb), smem, s, a);
   return hipGetLastError();
 }
 
-hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s) {
+// Does the instantiation this level takes have the fused histogram / Otsu variant (k_rowfilter<..., HIST = true>)?
+bool rowfilter_has_hist(const dsx::LevelPlan& lp) {
+  const int gf = lp.w >> 8, nt = (lp.w - (gf << 8) + 63) >> 6;
+  auto plan_is = [&](int m, int r0, int r1, int r2) {
+    return lp.M == m && lp.npass == 3 && lp.radix[0] == r0 && lp.radix[1] == r1 && lp.radix[2] == r2;
+  };
+  if (gf == 4 && nt == 1 && lp.K == 0 && plan_is(1026, 19, 9, 6)) return true;   // level 1 of a 2048-wide plane
+  if (gf == 2 && nt == 1 && lp.K > 0 && plan_is(1071, 17, 9, 7)) return true;    // level 2 of a 2048-wide plane
+  return false;
+}
+
+hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s, bool hist = false) {
   const int cpl = (a.M + 63) / 64;
   // slot structure of the row (full 256-value groups, 64-value tail slots) and pass list: the wide levels of
   // 2048-, 2000- and 1800-wide planes have instantiations with all of it as compile-time constants
@@ -266,11 +283,13 @@ hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStre
   if (cpl <= 10) return launch_rowfilter<10>(a, npairs, nb, s);
   if (cpl <= 18) {
     if (gf == 4 && nt == 1 && a.K == 0) {
-      if (plan_is(1026, 19, 9, 6)) return launch_rowfilter<18, 4, 1, 0, 1>(a, npairs, nb, s);
+      if (plan_is(1026, 19, 9, 6))
+        return hist ? launch_rowfilter<18, 4, 1, 0, 1, true>(a, npairs, nb, s) : launch_rowfilter<18, 4, 1, 0, 1>(a, npairs, nb, s);
       return launch_rowfilter<18, 4, 1, 0>(a, npairs, nb, s);
     }
     if (gf == 2 && nt == 1 && a.K > 0) {
-      if (plan_is(1071, 17, 9, 7)) return launch_rowfilter<18, 2, 1, 1, 2>(a, npairs, nb, s);
+      if (plan_is(1071, 17, 9, 7))
+        return hist ? launch_rowfilter<18, 2, 1, 1, 2, true>(a, npairs, nb, s) : launch_rowfilter<18, 2, 1, 1, 2>(a, npairs, nb, s);
       return launch_rowfilter<18, 2, 1, 1>(a, npairs, nb, s);
     }
     if (gf == 1 && nt == 4 && a.K > 0) {
@@ -344,8 +363,17 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   // (diagnosis only, results are wrong): what the chain would gain if that kernel were free
   static const int skip_hist = getenv("DSX_SKIP_HIST") ? atoi(getenv("DSX_SKIP_HIST")) : 0;
   static const int skip_row = getenv("DSX_SKIP_ROW") ? atoi(getenv("DSX_SKIP_ROW")) : 0;
+  // Levels 1 / 2 of the hot shapes: histogram + Otsu inside the row-filter kernel (k_rowfilter<..., HIST = true>), no
+  // separate pass over cH.  DSX_FUSE_HIST = bit mask of level indices (default 0 = off, see dsx_ctx::fuse_hist); the
+  // staged debug runs (dsx_set_stop_after) and profiling keep the separate kernels.
+  const int fuse_hist_env = ctx->fuse_hist;
+  int fused_levels = 0;
+  if (!generic && !ctx->profiling && ctx->stop_after == 0)
+    for (int l = 0; l < L && l < 2; ++l)
+      if (((fuse_hist_env >> l) & 1) && rowfilter_has_hist(p.lv[l])) fused_levels |= 1 << l;
   auto hist_level = [&](int l, hipStream_t hs) -> int {
     if ((skip_hist >> l) & 1) return DSX_OK;
+    if ((fused_levels >> l) & 1) return DSX_OK;
     const dsx::LevelPlan& lp = p.lv[l];
     dsx::HistArgs a;
     a.ws = v.ws;
@@ -470,6 +498,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.max_thr[0] = (float)ctx->cfg[0].max_threshold;
     a.max_thr[1] = (float)ctx->cfg[1].max_threshold;
     a.L = L;
+    a.fused_levels = fused_levels;
     LaunchScope ls(ctx, KC_OTSU);
     hipLaunchKernelGGL(dsx::k_otsu, dim3(L, nb), dim3(64), 0, s, a);
     DSX_HIP(hipGetLastError());
@@ -513,9 +542,20 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.kcut[1] = lp.kcut[1];
     a.inv_M = 1.0f / (float)lp.M;
     a.ablate = ctx->ablate;
+    const bool hist_here = ((fused_levels >> l) & 1) != 0;
+    if (hist_here) {
+      a.minmax = v.minmax;
+      a.hist = v.hist;
+      a.stats = v.stats;
+      a.thr_out = v.thr;
+      a.otsu_out = v.otsu;
+      a.max_thr[0] = (float)ctx->cfg[0].max_threshold;
+      a.max_thr[1] = (float)ctx->cfg[1].max_threshold;
+      a.sync_slot = l;
+    }
     const int npairs = (lp.h + 1) / 2;
     LaunchScope ls(ctx, KC_ROW);
-    DSX_HIP(dispatch_rowfilter(a, npairs, nb, rs));
+    DSX_HIP(dispatch_rowfilter(a, npairs, nb, rs, hist_here));
   }
   if (split_inv) DSX_HIP(hipEventRecord(v.ev[3], v.helper));
   if (ctx->stop_after == 2) return DSX_OK;
@@ -786,6 +826,7 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
   c->device = device;
   if (const char* ab = getenv("DSX_ABLATE")) c->ablate = atoi(ab);
   if (const char* gm = getenv("DSX_GRAPH")) c->graph_mode = atoi(gm) != 0 ? 1 : 0;
+  if (const char* fh = getenv("DSX_FUSE_HIST")) c->fuse_hist = atoi(fh);
   if (const char* ns = getenv("DSX_STREAMS")) c->n_streams = std::max(1, std::min(atoi(ns), (int)dsx_ctx::kMaxStreams));
   // DSX_PRIO=p0,p1,...: stream priority per sub-cohort stream (experiment hook; default: all equal)
   int prio[dsx_ctx::kMaxStreams] = {};
@@ -1078,10 +1119,14 @@ int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, i
     // float32 planes: the forward kernel flags pixels whose log(1 + x) is not finite (PlaneStats::flags); with at
     // least one decomposition level the reference raises ValueError for such a plane (numpy.histogram inside
     // threshold_otsu: "autodetected range of [nan, nan] is not finite")
-    if (in_dtype == DSX_F32 && p.L > 0) {
+    if (p.L > 0) {
       std::vector<dsx::PlaneStats> hs((size_t)nb);
       DSX_HIP(hipMemcpy(hs.data(), ctx->d_stats, sizeof(dsx::PlaneStats) * nb, hipMemcpyDeviceToHost));
       for (int k = 0; k < nb; ++k)
+        if (hs[(size_t)k].flags & 2ull)
+          return fail(ctx, DSX_EHIP, "plane " + std::to_string(start + k) + ": the plane barrier of the fused histogram / "
+                                     "row-filter kernel timed out (set DSX_FUSE_HIST=0)");
+      for (int k = 0; k < nb && in_dtype == DSX_F32; ++k)
         if (hs[(size_t)k].flags & 1ull)
           return fail(ctx, DSX_EVALUE, "plane " + std::to_string(start + k) +
                                            ": autodetected range of [nan, nan] is not finite (a pixel is NaN, "

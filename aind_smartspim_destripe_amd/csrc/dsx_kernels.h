@@ -95,8 +95,17 @@ struct PlaneStats {
   unsigned long long cnt_fg;   // pixels in the foreground class
   // bit 0: a float32 pixel was NaN, infinite or <= -1 (log(1 + x) is not finite: the reference dies in
   // numpy.histogram, filtering.py:188 -> skimage threshold_otsu); dsx_run_host turns it into DSX_EVALUE
+  // bit 1: the plane barrier of the fused histogram / row-filter kernel timed out (k_rowfilter<..., HIST>)
   unsigned long long flags;
+  // k_rowfilter<..., HIST = true> (levels 1, 2): blocks of a plane that have added their part of the histogram; set
+  // once the last of them has written the level's Otsu threshold; next work item of the launch (first plane of a part)
+  unsigned arrive[2], ticket[2];
+  unsigned pad0_[20];
+  // polled by the waiting blocks (plain loads): on a cache line of its own, away from the counters above
+  unsigned ready[2];
+  unsigned pad1_[30];
 };
+static_assert(sizeof(PlaneStats) == 256, "control block layout");
 
 // Half-sample symmetric extension index (np.pad 'symmetric'), any distance.
 __device__ __forceinline__ int reflect_idx(int i, int n) {
@@ -858,26 +867,22 @@ struct HistArgs {
   int rows_per_block;
 };
 
-__global__ __launch_bounds__(256) void k_hist(HistArgs a) {
-  __shared__ unsigned s_h[256];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int plane = blockIdx.y;
-  const unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
-  const float qmin = as_f32(~mm[0]), qmax = as_f32(mm[1]);
-  if (!(qmin < qmax)) return;  // constant cH^2: Otsu early-out, no histogram (block-uniform)
-  s_h[tid] = 0;
-  __syncthreads();
-  const float denom = qmax - qmin;
-  const float scale = 256.0f / denom;
-  // Bin of q = largest i with edges[i] <= q (numpy's estimate-then-correct rule ends there too).
-  // The edges are numpy.linspace's of the reference's pinned NumPy 1.26.4: float32 end points are
-  // promoted to float64, edges[i] = i * ((max - min) / 256) + min in float64 (separate multiply and
-  // add), then rounded to float32.  The estimate (q - qmin) * scale is within 1e-4 of the exact
-  // position, so only values within 1e-3 of an integer need the comparison against the actual edges.
-  const double first64 = (double)qmin, step64 = ((double)qmax - (double)qmin) / 256.0;
-  auto edge = [&](int i) { return (float)__dadd_rn(__dmul_rn((double)i, step64), first64); };
-  const float off = -qmin * scale;
-  auto bin_of = [&](float q) {
+// Bin of q = largest i with edges[i] <= q (numpy's estimate-then-correct rule ends there too).
+// The edges are numpy.linspace's of the reference's pinned NumPy 1.26.4: float32 end points are
+// promoted to float64, edges[i] = i * ((max - min) / 256) + min in float64 (separate multiply and
+// add), then rounded to float32.  The estimate (q - qmin) * scale is within 1e-4 of the exact
+// position, so only values within 1e-3 of an integer need the comparison against the actual edges.
+struct HistBins {
+  float qmin, qmax, scale, off;
+  double first64, step64;
+  __device__ __forceinline__ HistBins(float lo, float hi) : qmin(lo), qmax(hi) {
+    scale = 256.0f / (qmax - qmin);
+    off = -qmin * scale;
+    first64 = (double)qmin;
+    step64 = ((double)qmax - (double)qmin) / 256.0;
+  }
+  __device__ __forceinline__ float edge(int i) const { return (float)__dadd_rn(__dmul_rn((double)i, step64), first64); }
+  __device__ __forceinline__ int operator()(float q) const {
     const float fi = fmaf(q, scale, off);  // = (q - qmin) * scale to a few ulp of 256
     int idx = min((int)fi, 255);
     const float fr = __builtin_amdgcn_fractf(fi);  // 0 for the clamped q == qmax: takes the exact path
@@ -889,7 +894,19 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
       idx = max(idx, 0);
     }
     return idx;
-  };
+  }
+};
+
+__global__ __launch_bounds__(256) void k_hist(HistArgs a) {
+  __shared__ unsigned s_h[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int plane = blockIdx.y;
+  const unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
+  const float qmin = as_f32(~mm[0]), qmax = as_f32(mm[1]);
+  if (!(qmin < qmax)) return;  // constant cH^2: Otsu early-out, no histogram (block-uniform)
+  s_h[tid] = 0;
+  __syncthreads();
+  const HistBins bin_of(qmin, qmax);
   // the four lowest bins hold most of the mass: byte-packed per-lane counters, flushed before overflow
   unsigned packed = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, since_flush = 0;
   auto count = [&](int idx) {
@@ -980,7 +997,72 @@ struct OtsuArgs {
   double* means; // [B][2]
   float max_thr[2];
   int L;
+  int fused_levels;  // bit l: level index l takes its threshold from the fused histogram / row-filter kernel
 };
+
+// Otsu value of one plane and level from its 256-bin histogram, by ONE wave (64 lanes): returns the value on every
+// lane.  scratch: 6 x 256 doubles of LDS.  The caller applies sqrt / the threshold cap.
+// COHERENT: the counts were made by atomics of other blocks of the SAME kernel (k_rowfilter<..., HIST>): read them past
+// this compute die's L2 (device-scope atomic loads) instead of fencing the whole cache.
+template <bool COHERENT = false>
+__device__ __forceinline__ double otsu_from_hist(float q_lo, float q_hi, const unsigned* h, double* scratch, int lane) {
+  // The class statistics are accumulated sequentially in numpy's order (cumsum forward for class 1,
+  // cumsum over the reversed arrays for class 2): empty bins then give bit-identical variances on both
+  // sides, and "first maximum" picks the same bin as np.argmax.  Only the two running sums are
+  // sequential (lane 0 forward, lane 1 backward, additions only); products, quotients, variances and
+  // the arg-max run on all lanes.
+  double* s_cnt = scratch;
+  double* s_cb = scratch + 256;
+  double (*s_w)[256] = (double (*)[256])(scratch + 512);
+  double (*s_s)[256] = (double (*)[256])(scratch + 1024);
+  if (!(q_lo < q_hi)) return (double)q_lo;  // all values equal: threshold_otsu returns that value
+  // float32 bin edges exactly as k_hist builds them (numpy.linspace of NumPy 1.26.4), float32 bin
+  // centres (edges[:-1] + edges[1:]) / 2 as in skimage's threshold_otsu on a float32 image; the class
+  // statistics below are float64 (counts.astype(float))
+  const double first = (double)q_lo, last = (double)q_hi;
+  const double step = (last - first) / 256.0;
+  auto edge = [&](int i) { return (i == 256) ? q_hi : (float)__dadd_rn(__dmul_rn((double)i, step), first); };
+  auto centre = [&](int g) { return __fmul_rn(__fadd_rn(edge(g), edge(g + 1)), 0.5f); };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int g = lane + 64 * i;
+    const double c = COHERENT ? (double)__hip_atomic_load(h + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (double)h[g];
+    s_cnt[g] = c;
+    s_cb[g] = c * (double)centre(g);
+  }
+  wave_sync();
+  if (lane < 2) {
+    double w = 0.0, sacc = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 256; ++k) {
+      const int g = lane ? 255 - k : k;
+      w += s_cnt[g];
+      sacc += s_cb[g];
+      s_w[lane][g] = w;
+      s_s[lane][g] = sacc;
+    }
+  }
+  wave_sync();
+  // variance12[g] = weight1[g] weight2[g + 1] (mean1[g] - mean2[g + 1])^2, g = 0 .. 254; first maximum
+  double best = -1.0;
+  int best_g = 0;
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {
+    const int g = lane + 64 * i;
+    if (g < 255) {
+      const double d = s_s[0][g] / s_w[0][g] - s_s[1][g + 1] / s_w[1][g + 1];
+      const double var = (s_w[0][g] * s_w[1][g + 1]) * (d * d);
+      if (var >= best) { best = var; best_g = g; }  // descending g: ties keep the lower bin
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ob = __shfl_xor(best, o);
+    const int og = __shfl_xor(best_g, o);
+    if (ob > best || (ob == best && og < best_g)) { best = ob; best_g = og; }
+  }
+  return (double)centre(best_g);
+}
 
 __global__ __launch_bounds__(64) void k_otsu(OtsuArgs a) {
   const int lvl = blockIdx.x, plane = blockIdx.y, lane = threadIdx.x;
@@ -995,67 +1077,12 @@ __global__ __launch_bounds__(64) void k_otsu(OtsuArgs a) {
     a.means[2 * plane] = fore;
     a.means[2 * plane + 1] = back;
   }
+  if ((a.fused_levels >> lvl) & 1) return;  // this level's threshold comes out of k_rowfilter<..., HIST = true>
   const long long pl = (long long)plane * a.L + lvl;
   const unsigned* mm = a.minmax + pl * 2;
   const float q_lo = as_f32(~mm[0]), q_hi = as_f32(mm[1]);
-  // The class statistics are accumulated sequentially in numpy's order (cumsum forward for class 1,
-  // cumsum over the reversed arrays for class 2): empty bins then give bit-identical variances on both
-  // sides, and "first maximum" picks the same bin as np.argmax.  Only the two running sums are
-  // sequential (lane 0 forward, lane 1 backward, additions only); products, quotients, variances and
-  // the arg-max run on all lanes.
-  __shared__ double s_cnt[256], s_cb[256], s_w[2][256], s_s[2][256];
-  double otsu;
-  if (!(q_lo < q_hi)) {
-    otsu = (double)q_lo;  // all values equal: threshold_otsu returns that value
-  } else {
-    // float32 bin edges exactly as k_hist builds them (numpy.linspace of NumPy 1.26.4), float32 bin
-    // centres (edges[:-1] + edges[1:]) / 2 as in skimage's threshold_otsu on a float32 image; the class
-    // statistics below are float64 (counts.astype(float))
-    const double first = (double)q_lo, last = (double)q_hi;
-    const double step = (last - first) / 256.0;
-    auto edge = [&](int i) { return (i == 256) ? q_hi : (float)__dadd_rn(__dmul_rn((double)i, step), first); };
-    auto centre = [&](int g) { return __fmul_rn(__fadd_rn(edge(g), edge(g + 1)), 0.5f); };
-    const unsigned* h = a.hist + pl * 256;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int g = lane + 64 * i;
-      const double c = (double)h[g];
-      s_cnt[g] = c;
-      s_cb[g] = c * (double)centre(g);
-    }
-    __syncthreads();
-    if (lane < 2) {
-      double w = 0.0, sacc = 0.0;
-#pragma unroll 8
-      for (int k = 0; k < 256; ++k) {
-        const int g = lane ? 255 - k : k;
-        w += s_cnt[g];
-        sacc += s_cb[g];
-        s_w[lane][g] = w;
-        s_s[lane][g] = sacc;
-      }
-    }
-    __syncthreads();
-    // variance12[g] = weight1[g] weight2[g + 1] (mean1[g] - mean2[g + 1])^2, g = 0 .. 254; first maximum
-    double best = -1.0;
-    int best_g = 0;
-#pragma unroll
-    for (int i = 3; i >= 0; --i) {
-      const int g = lane + 64 * i;
-      if (g < 255) {
-        const double d = s_s[0][g] / s_w[0][g] - s_s[1][g + 1] / s_w[1][g + 1];
-        const double var = (s_w[0][g] * s_w[1][g + 1]) * (d * d);
-        if (var >= best) { best = var; best_g = g; }  // descending g: ties keep the lower bin
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double ob = __shfl_xor(best, o);
-      const int og = __shfl_xor(best_g, o);
-      if (ob > best || (ob == best && og < best_g)) { best = ob; best_g = og; }
-    }
-    otsu = (double)centre(best_g);
-  }
+  __shared__ double s_scratch[6 * 256];
+  const double otsu = otsu_from_hist(q_lo, q_hi, a.hist + pl * 256, s_scratch, lane);
   if (lane == 0) {
     const double t = fmin(otsu >= 0 ? sqrt(otsu) : 0.0, (double)a.max_thr[cfg]);
     a.otsu[pl] = (float)otsu;
@@ -1083,6 +1110,16 @@ struct RowArgs {
   int kcut[2];         // per config: the gains vanish for kcut < k < M - kcut
   float inv_M;
   int ablate;          // diagnosis only (DSX_ABLATE): 1 = no median, 2 = no FFT passes, 4 = no spectral step
+  // HIST (k_rowfilter<..., HIST = true>): the level's histogram, Otsu value and threshold are made HERE, from the rows
+  // the waves hold anyway -- the separate histogram pass over cH (4.2 MB per plane at level 1) goes away
+  const unsigned* minmax;  // [B][L][2]
+  unsigned* hist;          // [B][L][256]
+  PlaneStats* stats;       // [B]: arrive / ready / ticket words, flags
+  float* thr_out;          // [B][L]
+  float* otsu_out;         // [B][L]
+  float max_thr[2];
+  int blocks_per_plane;
+  int sync_slot;           // index into PlaneStats::arrive / ready / ticket (0: level 1, 1: level 2)
 };
 
 __device__ __forceinline__ unsigned f32_key(float v) {
@@ -1336,7 +1373,13 @@ constexpr int kRowMaxWaves = 8;  // waves (row pairs) per block; they share one 
 // (the hot shapes get their own instantiation without the per-group guards); -1: taken from a.w.
 // HALO_: 0 = direct transform (K == 0), 1 = periodic halo (K > 0), -1 = decided at run time.
 // PLAN_: compile-time FFT plan (StaticFft), 0 = the pass list of RowArgs.
-template <int CPL, int GF_ = -1, int NT_ = -1, int HALO_ = -1, int PLAN_ = 0>
+// HIST: the kernel also makes the level's histogram, Otsu value and threshold (see RowArgs).  Every block adds the
+// values of its rows to the plane's histogram, then the blocks of a plane meet at a barrier in global memory; the last
+// one to arrive computes the Otsu threshold and releases the others, which have kept their rows in registers.  Work
+// items are handed out by a ticket counter, plane by plane, so every block a waiting block depends on has a LOWER
+// ticket, i.e. is already running (or done): no deadlock whatever the dispatch order, and at most the blocks of one
+// incomplete plane per launch wait for slots.  The wait is bounded all the same (PlaneStats::flags bit 1).
+template <int CPL, int GF_ = -1, int NT_ = -1, int HALO_ = -1, int PLAN_ = 0, bool HIST = false>
 __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void k_rowfilter(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1345,10 +1388,22 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   const bool halo = (HALO_ >= 0) ? (HALO_ != 0) : (K > 0);
   float2* s_tw = dsx_smem;
   float2* buf = dsx_smem + (long long)M * (1 + wave);
-  const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
+  // HIST: one word of block-wide exchange, 16 KB into the FFT buffers (behind the histogram / Otsu scratch; no static
+  // LDS: the dynamic allocation may be the whole 160 KB)
+  volatile int* s_item = (volatile int*)(dsx_smem + M + 2048);
+  int item_x = blockIdx.x, item_plane = blockIdx.y;
+  if (HIST) {
+    if (tid == 0) *s_item = (int)atomicAdd(&a.stats[0].ticket[a.sync_slot], 1u);
+    __syncthreads();
+    const int item = *s_item;
+    item_plane = item / a.blocks_per_plane;
+    item_x = item - item_plane * a.blocks_per_plane;
+    __syncthreads();
+  }
+  const int pair = item_x * (blockDim.x >> 6) + wave;
   const int npairs = (a.h + 1) >> 1;
   const bool live = pair < npairs;  // (waves past the last pair still help loading the twiddles)
-  const int plane = blockIdx.y;
+  const int plane = item_plane;
   const int r0 = live ? 2 * pair : 0;
   const bool has_b = (r0 + 1) < a.h;
   const int cfg = a.cfg[plane];
@@ -1363,16 +1418,21 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   const int nt = (NT_ >= 0) ? NT_ : ((N - tail0 + 63) >> 6);    // lane-strided tail slots
   const int tn = tail0 + lane;                 // this lane's element of tail slot 0 (+ 64 per slot)
 
-  if (a.lvl >= a.lvl_active[cfg]) {  // this config does not filter this level: Delta = 0 (block-uniform)
+  const bool inactive = a.lvl >= a.lvl_active[cfg];  // this config does not filter this level: Delta = 0 (block-uniform)
+  auto zero_rows = [&]() {
     if (live) {
       for (int n = 4 * lane; n < N; n += 4 * kWave) {
         *(float4*)(rowa + n) = make_float4(0.f, 0.f, 0.f, 0.f);
         if (has_b) *(float4*)(rowb + n) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+  };
+  if (!HIST && inactive) {
+    zero_rows();
     return;
   }
-  const float thr = a.thr[(long long)plane * a.L + a.lvl];
+  float thr = 0.f;
+  if (!HIST) thr = a.thr[(long long)plane * a.L + a.lvl];
 
   // ---- load both rows; background = masked entries zeroed (filtering.py:195-197) -------------
   // issue the row loads, THEN stage the twiddles: the two global latencies overlap
@@ -1397,7 +1457,95 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
     }
   }
   for (int i = tid; i < M; i += blockDim.x) s_tw[i] = a.tw[i];
-  __syncthreads();  // the only block-wide barrier: afterwards every wave works on its own rows
+  __syncthreads();  // the only block-wide barrier (without HIST): afterwards every wave works on its own rows
+  if (HIST) {
+    // ---- histogram of q = cH^2 over the rows of this block (numpy rule, HistBins), into the plane's 256 bins ----
+    const long long pl = (long long)plane * a.L + a.lvl;
+    const unsigned* mm = a.minmax + pl * 2;
+    const float qmin = as_f32(~mm[0]), qmax = as_f32(mm[1]);
+    unsigned* s_h = (unsigned*)(dsx_smem + M);  // the waves' FFT buffers are not in use yet
+    PlaneStats* ps = a.stats + plane;
+    if (qmin < qmax) {  // (constant cH^2: no histogram, Otsu returns the value)
+      if (tid < 256) s_h[tid] = 0;
+      __syncthreads();
+      if (live) {
+        const HistBins bin_of(qmin, qmax);
+        // the four lowest bins hold most of the mass: byte-packed per-lane counters (at most 2 x 36 values per lane)
+        unsigned packed = 0;
+        auto count = [&](float x) {
+          const int idx = bin_of(x * x);
+          packed += (idx < 4) ? (1u << (8 * idx)) : 0u;
+          if (idx >= 4) atomicAdd(&s_h[idx], 1u);
+        };
+#pragma unroll
+        for (int g = 0; g < GV; ++g) {
+          if (g < gf) {
+            count(ra4[g].x); count(ra4[g].y); count(ra4[g].z); count(ra4[g].w);
+            if (has_b) { count(rb4[g].x); count(rb4[g].y); count(rb4[g].z); count(rb4[g].w); }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k < nt && tn + 64 * k < N) {
+            count(rta[k]);
+            if (has_b) count(rtb[k]);
+          }
+        }
+        const unsigned c0 = __reduce_add_sync(~0ull, packed & 0xFFu), c1 = __reduce_add_sync(~0ull, (packed >> 8) & 0xFFu);
+        const unsigned c2 = __reduce_add_sync(~0ull, (packed >> 16) & 0xFFu), c3 = __reduce_add_sync(~0ull, packed >> 24);
+        if (lane == 0) {
+          if (c0) atomicAdd(&s_h[0], c0);
+          if (c1) atomicAdd(&s_h[1], c1);
+          if (c2) atomicAdd(&s_h[2], c2);
+          if (c3) atomicAdd(&s_h[3], c3);
+        }
+      }
+      __syncthreads();
+      if (tid < 256) {
+        const unsigned n = s_h[tid];
+        if (n) atomicAdd(&a.hist[pl * 256 + tid], n);
+      }
+    }
+    // ---- plane barrier: the last block to arrive turns the histogram into the threshold ----
+    // Everything that crosses blocks here is a device-scope atomic (read-modify-write, load or store: performed past
+    // the compute die's L2), ordered by waiting for its completion -- NOT by agent-scope fences, which write back and
+    // invalidate the whole L2 of the die every time (measured: 3 x slower chain, other streams' kernels included).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's histogram atomics are complete
+    __syncthreads();
+    if (tid == 0) *s_item = (atomicAdd(&ps->arrive[a.sync_slot], 1u) == (unsigned)a.blocks_per_plane - 1u) ? 1 : 0;
+    __syncthreads();
+    const bool last_block = *s_item != 0;  // block-uniform
+    if (last_block) {
+      if (wave == 0) {
+        double* scratch = (double*)(dsx_smem + M);  // 12 KB over the first FFT buffers
+        const double otsu = otsu_from_hist<true>(qmin, qmax, a.hist + pl * 256, scratch, lane);
+        if (lane == 0) {
+          const double t = fmin(otsu >= 0 ? sqrt(otsu) : 0.0, (double)a.max_thr[cfg]);
+          __hip_atomic_store(a.otsu_out + pl, (float)otsu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a.thr_out + pl, (float)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // both stores are complete before the flag goes up
+          __hip_atomic_store(&ps->ready[a.sync_slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    } else if (tid == 0) {
+      // every block this one waits for holds a lower ticket and is running; the bound only guards against a
+      // runtime that breaks that promise (~2 s), and is reported instead of hanging the device
+      unsigned spins = 0;
+      while (__hip_atomic_load(&ps->ready[a.sync_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1u << 18)) {
+          atomicOr(&ps->flags, 2ull);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    thr = __hip_atomic_load(a.thr_out + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by another block
+    if (inactive) {
+      zero_rows();
+      return;
+    }
+  }
   if (!live) return;
 
   // Background values (masked entries zeroed, filtering.py:195-197) stay in registers as floats; slots past

@@ -663,3 +663,36 @@ def test_graph_replay_is_bit_identical_to_eager_launches(monkeypatch):
             e2.close()
     finally:
         e.close()
+
+
+def test_fused_histogram_row_filter_is_bit_identical_to_the_separate_kernels(monkeypatch):
+    """Levels 1 / 2 of 2048-wide planes make their histogram, Otsu value and threshold inside the row-filter kernel
+    (k_rowfilter<..., HIST>: ticketed work items, plane barrier in global memory).  Integer counts and the same Otsu
+    code: results, Otsu values and thresholds must be bit-identical to the chain with k_hist / k_otsu (DSX_FUSE_HIST=0),
+    for an unsplit cohort (helper stream), a cohort split over the four streams, and a plane of constant rows (constant
+    cH^2: no histogram at all)."""
+    h, w = 2048, 2048
+    bank = synth.synthetic_bank(6, h, w)
+    flatp = np.full((h, w), 300, np.uint16)  # cH == 0 everywhere: min == max at every level
+    rows = np.repeat((100 + 50 * np.arange(h, dtype=np.uint16) % 7)[:, None], w, axis=1).astype(np.uint16)
+    stack = np.concatenate([bank, flatp[None], rows[None], synth.synthetic_stack(64, h, w, bank=bank)])  # 72 planes
+    res = {}
+    for mode in ("0", "1", "3"):
+        monkeypatch.setenv("DSX_FUSE_HIST", mode)
+        e = eng_mod.DestripeEngine(0)
+        try:
+            e.plan(h, w, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT, max_batch=72)
+            small = e.run(stack[:8], out_dtype=np.float32)            # one part, helper stream
+            thr_small = [[e.thresholds(k, lv) for lv in range(e.levels)] for k in range(8)]
+            big, cfg = e.run(stack, out_dtype=np.uint16, return_cfg=True)  # 72 planes: 4 parts of 18
+            thr_big = [[e.thresholds(k, lv) for lv in range(e.levels)] for k in (0, 6, 7, 17, 18, 40, 71)]
+            res[mode] = (small, thr_small, big, cfg, thr_big)
+        finally:
+            e.close()
+    for mode in ("1", "3"):
+        for a, b in zip(res[mode], res["0"]):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b), err_msg="DSX_FUSE_HIST=" + mode)
+    # and the reference: plane 1 of the stack against the oracle
+    ref = orc.filter_stripes(stack[1], "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT)
+    d = np.abs(res["1"][2][1].astype(np.int64) - ref.astype(np.uint16).astype(np.int64))
+    assert d.max() <= 1
