@@ -111,7 +111,8 @@ int dsx_constants_device(const dsx_ctx* ctx, void** d_ptr, size_t* bytes);
 /* ---- run ---------------------------------------------------------------------------------- */
 /* n planes, C-order [n, H, W] in, [n, H', W'] out.  out_dtype DSX_F32: exp(y)+1 (after shading
  * if planned, before the integer cast); DSX_U16: clip to [0, 65535] and truncate.
- * cfg_used (nullable): per plane 1 == cells_config, 0 == no_cells_config.                     */
+ * cfg_used (nullable): per plane 1 == cells_config, 0 == no_cells_config (0 throughout when neither
+ * config runs a decomposition level: the result is image + 2 either way and no statistic is made). */
 int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, int out_dtype,
                  int32_t* cfg_used);
 /* Device pointers; asynchronous on the context stream (call dsx_sync).  d_cfg_used nullable. */

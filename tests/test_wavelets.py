@@ -220,3 +220,47 @@ def test_gpu_wavelet_batch_configs_statistic_shading_and_casts():
     # level 0 is wavelet-independent: image + 2
     z = filtering.log_space_fft_filtering(x, wavelet="coif2", level=0, sigma=64, max_threshold=4)
     np.testing.assert_allclose(z, x.astype(np.float64) + 2.0, rtol=1e-6)
+
+
+def test_rbio31_float32_spread_of_the_reference_algorithm_itself():
+    """rbio3.1 (4 taps, dec_lo = [-0.35, 1.06, 1.06, -0.35]) is the one PyWavelets bank whose synthesis amplifies float32
+    round-off beyond the 1e-4 of the parity statement at full depth: the REFERENCE ALGORITHM's own float32 regime (float32
+    planes, the Zarr path) and float64 regime (uint16 planes) differ by 1e-3 on a 260 x 331 plane, every other bank by
+    < 3e-5 (the few with a larger MAXIMUM -- coif1, rbio3.9 here -- differ by a threshold decision, with the usual median).
+    CPU: the oracle in both regimes."""
+    import warnings
+
+    img = synth.synthetic_plane(3, 260, 331)
+    spread = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name in ("rbio3.1", "bior3.1", "rbio2.2", "db3", "sym8"):
+            bank = wavelets.filter_bank(name)
+            a = orc.log_space_fft_filtering(img, wavelet=bank, level=None, sigma=128, max_threshold=12)
+            b = orc.log_space_fft_filtering(img.astype(np.float32), wavelet=bank, level=None, sigma=128, max_threshold=12)
+            r = np.abs(a - b) / np.abs(a)
+            spread[name] = (float(r.max()), float(np.median(r)))
+    assert spread["rbio3.1"][0] > 3e-4 and spread["rbio3.1"][1] > 4e-6, spread
+    for name in ("bior3.1", "rbio2.2", "db3", "sym8"):
+        assert spread[name][0] < 5e-5 and spread[name][1] < 4e-6, (name, spread)
+
+
+@pytest.mark.gpu
+def test_gpu_rbio31_within_the_reference_s_own_regime_spread():
+    """The engine on rbio3.1 at full depth: median as for every other bank, maximum within 5e-3 (the reference's own two
+    regimes are 1e-3 apart, see the CPU test above); at depth 2 the 1e-4 statement holds as usual."""
+    from aind_smartspim_destripe_amd import filtering
+
+    img = synth.synthetic_plane(3, 260, 331)
+    bank = wavelets.filter_bank("rbio3.1")
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = filtering.log_space_fft_filtering(img.astype(np.float32), wavelet="rbio3.1", level=None, sigma=128, max_threshold=12)
+        ref = orc.log_space_fft_filtering(img.astype(np.float32), wavelet=bank, level=None, sigma=128, max_threshold=12)
+        r = np.abs(got - ref) / np.abs(ref)
+        assert float(np.median(r)) < 2e-5 and float(r.max()) < 5e-3, (float(np.median(r)), float(r.max()))
+        got2 = filtering.log_space_fft_filtering(img.astype(np.float32), wavelet="rbio3.1", level=2, sigma=128, max_threshold=12)
+        ref2 = orc.log_space_fft_filtering(img.astype(np.float32), wavelet=bank, level=2, sigma=128, max_threshold=12)
+        assert _rel(got2, ref2) < 1e-4

@@ -1,20 +1,22 @@
 #!/usr/bin/env python3
 """Randomised parity run: engine (through the C ABI) against the CPU oracle on random plane shapes, input dtypes, batch
 sizes and output dtypes, with the statement of tests/parity_util.py (every pixel within 1e-4 once the counted
-near-threshold mask decisions are forced into the oracle).  usage: python tools/fuzz_parity.py [cases] [seed]
+near-threshold mask decisions are forced into the oracle).  usage: python tools/fuzz_parity.py [cases] [seed] [wavelets]
+(third argument "wavelets": a random PyWavelets wavelet per case -- 2 ... 102 taps -- through the tap-count-generic level
+kernels, on small planes down to a few pixels, the oracle running on the same filter bank)
 Shapes favour the awkward ones: widths around multiples of 4 / 8 / 122 / 244 / 256 (strip and lane-pair boundaries of
 the march kernels), odd heights, planes of one strip and of many."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from aind_smartspim_destripe_amd import engine as eng_mod, filtering, synth
+from aind_smartspim_destripe_amd import engine as eng_mod, filtering, synth, wavelets
 from oracle import destripe_oracle as orc
 from parity_util import check_plane, gpu_deltas, oracle_plane
 
 
 
-def run(cases=40, seed=2026, eng=None):
+def run(cases=40, seed=2026, eng=None, any_wavelet=False):
     """``cases`` random cases; raises AssertionError on the first plane that violates the parity statement.
     Returns (planes checked, planes that needed the float32 regime of the reference)."""
     rng = np.random.default_rng(seed)
@@ -28,17 +30,30 @@ def run(cases=40, seed=2026, eng=None):
         if rng.random() < 0.6: w = (w + 3) & ~3          # fused kernels need a multiple of 4
         if rng.random() < 0.3: w = (w + 7) & ~7          # lane-pair I/O of the final kernel: multiple of 8
         h = int(rng.integers(40, 700))
+        name = "db3"
+        if any_wavelet:
+            # (dmey is refused; rbio3.1 amplifies float32 round-off beyond 1e-4 at depth -- the reference's own float32
+            # and float64 regimes differ by 1e-3 there -- and has its own test with its own bound, tests/test_wavelets.py)
+            name = str(rng.choice([x for x in wavelets.wavelist() if x not in ("dmey", "rbio3.1")]))
+            w, h = int(rng.integers(6, 420)), int(rng.integers(6, 300))
         n = int(rng.integers(1, 5))
         as_f32 = rng.random() < 0.3
         # random filter parameters: decomposition depth, low-pass width, threshold cap, fg/bg decision level
-        cells = {"wavelet": "db3", "level": [None, None, 1, 2, 3, 5][int(rng.integers(0, 6))],
+        cells = {"wavelet": name, "level": [None, None, 1, 2, 3, 5][int(rng.integers(0, 6))],
                  "sigma": float(rng.choice([16, 64, 100, 250])), "max_threshold": float(rng.choice([0.5, 3, 12]))}
-        nocells = {"wavelet": "db3", "level": [None, None, 1, 2, 4][int(rng.integers(0, 5))],
+        nocells = {"wavelet": name, "level": [None, None, 1, 2, 4][int(rng.integers(0, 5))],
                    "sigma": float(rng.choice([32, 128, 512])), "max_threshold": float(rng.choice([1, 12, 100]))}
         high_int = int(rng.choice([100, 160, 2500]))
+        # the oracle takes the filter bank itself (it knows db3 by name only)
+        ocells, onocells = (dict(c, wavelet=wavelets.filter_bank(name)) if any_wavelet else c for c in (cells, nocells))
         planes = np.stack([synth.synthetic_plane(int(rng.integers(0, 1000)), h, w) for _ in range(n)])
         src = planes.astype(np.float32) if as_f32 else planes
-        deltas = gpu_deltas(eng, src, high_int=high_int, cells=cells, nocells=nocells)
+        try:
+            deltas = gpu_deltas(eng, src, high_int=high_int, cells=cells, nocells=nocells)
+        except ValueError as e:
+            if "odd plane" in str(e):  # documented limit: one config with levels, one without, on an odd plane
+                continue
+            raise
         out, cfg = filtering.destripe_planes(src, "X_0_Y_0", nocells, cells, None,
                                              high_int, out_dtype=np.float32, return_config=True, max_batch=n)
         for k in range(n):
@@ -49,11 +64,13 @@ def run(cases=40, seed=2026, eng=None):
             err = None
             for regime in ((np.float32,) if as_f32 else (np.uint16, np.float32)):
                 img = src[k].astype(regime)
-                which, _, _, ref, stages = oracle_plane(img, high_int=high_int, cells=cells, nocells=nocells)
-                assert int(cfg[k]) == which, (h, w, k)
-                cfgd = cells if which else nocells
+                which, _, _, ref, stages = oracle_plane(img, high_int=high_int, cells=ocells, nocells=onocells)
+                # (no decomposition level at all -- long filters on small planes: the result is image + 2 whatever the
+                # config, the statistic is not computed and cfg_used reads 0)
+                assert int(cfg[k]) == which or eng.levels == 0, (h, w, k)
+                cfgd = ocells if which else onocells
                 try:
-                    check_plane(out[k], img, deltas[k], ((h, w), np.dtype(regime).name, k), cfgd, max_flips, ref=ref, stages=stages)
+                    check_plane(out[k], img, deltas[k], ((h, w), np.dtype(regime).name, k, name), cfgd, max_flips, ref=ref, stages=stages)
                     err = None
                     break
                 except AssertionError as e:
@@ -85,4 +102,7 @@ def run(cases=40, seed=2026, eng=None):
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+    import warnings
+    warnings.simplefilter("ignore")  # "level too high" for long filters on small planes
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 2026,
+        any_wavelet=len(sys.argv) > 3 and sys.argv[3] == "wavelets")
