@@ -425,7 +425,7 @@ def destripe_zarr(
     rank=0,
     world_size=1,
     device=None,
-    compressor=None,
+    compressor="blosc",
     logger=None,
     device_retile=None,
     io_threads=8,
@@ -433,6 +433,10 @@ def destripe_zarr(
     group=None,
 ):
     """Chunk map of ``destripe_zarr`` (``zarr_destriper.py:909-1211``) over a Zarr-v2 directory store.
+
+    ``compressor``: codec of the output array; the default is the reference's,
+    ``Blosc(cname="zstd", clevel=3, shuffle=SHUFFLE)`` (``:1066-1074``); ``None`` (raw chunks), ``"zlib"`` or a
+    numcodecs config dict are accepted as well.
 
     Every rank opens the same input / output arrays and processes its own z-range
     (chunk-aligned, so no two ranks touch one output chunk).  Blocks cover the full Y x X plane in
@@ -521,7 +525,7 @@ def destripe_channel(
     rank=0,
     world_size=1,
     device=None,
-    compressor=None,
+    compressor="blosc",
     n_levels=3,
     logger=None,
     group=None,
