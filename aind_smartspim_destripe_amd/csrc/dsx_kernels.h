@@ -1002,8 +1002,9 @@ struct OtsuArgs {
 
 // Otsu value of one plane and level from its 256-bin histogram, by ONE wave (64 lanes): returns the value on every
 // lane.  scratch: 6 x 256 doubles of LDS.  The caller applies sqrt / the threshold cap.
-// COHERENT: the counts were made by atomics of other blocks of the SAME kernel (k_rowfilter<..., HIST>): read them past
-// this compute die's L2 (device-scope atomic loads) instead of fencing the whole cache.
+// COHERENT: the counts were made by atomics of other blocks of the SAME kernel (k_rowfilter<..., HIST>): read them with
+// read-modify-write atomics (performed where the other dies' atomics were) instead of fencing the whole L2.  (Device-
+// scope atomic LOADS are not enough on this chip: a line once loaded into the die's L2 keeps answering them.)
 template <bool COHERENT = false>
 __device__ __forceinline__ double otsu_from_hist(float q_lo, float q_hi, const unsigned* h, double* scratch, int lane) {
   // The class statistics are accumulated sequentially in numpy's order (cumsum forward for class 1,
@@ -1026,7 +1027,7 @@ __device__ __forceinline__ double otsu_from_hist(float q_lo, float q_hi, const u
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int g = lane + 64 * i;
-    const double c = COHERENT ? (double)__hip_atomic_load(h + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (double)h[g];
+    const double c = COHERENT ? (double)atomicAdd(const_cast<unsigned*>(h) + g, 0u) : (double)h[g];
     s_cnt[g] = c;
     s_cb[g] = c * (double)centre(g);
   }
@@ -1507,9 +1508,11 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
       }
     }
     // ---- plane barrier: the last block to arrive turns the histogram into the threshold ----
-    // Everything that crosses blocks here is a device-scope atomic (read-modify-write, load or store: performed past
-    // the compute die's L2), ordered by waiting for its completion -- NOT by agent-scope fences, which write back and
-    // invalidate the whole L2 of the die every time (measured: 3 x slower chain, other streams' kernels included).
+    // Everything that crosses blocks here is a device-scope read-modify-write atomic (performed past the compute die's
+    // L2), ordered by waiting for its completion -- NOT by agent-scope fences, which write back and invalidate the whole
+    // L2 of the die every time (measured: 3 x slower chain, other streams' kernels included), and not by atomic loads
+    // / stores either: polled with device-scope atomic loads the flag below was now and then never seen (a stale line
+    // in the die's L2 keeps answering; found by the test suite as a barrier time-out).
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's histogram atomics are complete
     __syncthreads();
     if (tid == 0) *s_item = (atomicAdd(&ps->arrive[a.sync_slot], 1u) == (unsigned)a.blocks_per_plane - 1u) ? 1 : 0;
@@ -1521,18 +1524,18 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
         const double otsu = otsu_from_hist<true>(qmin, qmax, a.hist + pl * 256, scratch, lane);
         if (lane == 0) {
           const double t = fmin(otsu >= 0 ? sqrt(otsu) : 0.0, (double)a.max_thr[cfg]);
-          __hip_atomic_store(a.otsu_out + pl, (float)otsu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(a.thr_out + pl, (float)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // both stores are complete before the flag goes up
-          __hip_atomic_store(&ps->ready[a.sync_slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicExch(reinterpret_cast<unsigned*>(a.otsu_out + pl), as_u32((float)otsu));
+          atomicExch(reinterpret_cast<unsigned*>(a.thr_out + pl), as_u32((float)t));
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // both are complete before the flag goes up
+          atomicExch(&ps->ready[a.sync_slot], 1u);
         }
       }
     } else if (tid == 0) {
       // every block this one waits for holds a lower ticket and is running; the bound only guards against a
       // runtime that breaks that promise (~2 s), and is reported instead of hanging the device
       unsigned spins = 0;
-      while (__hip_atomic_load(&ps->ready[a.sync_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        __builtin_amdgcn_s_sleep(32);
+      while (atomicAdd(&ps->ready[a.sync_slot], 0u) == 0u) {
+        __builtin_amdgcn_s_sleep(64);
         if (++spins > (1u << 18)) {
           atomicOr(&ps->flags, 2ull);
           break;
@@ -1540,7 +1543,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
       }
     }
     __syncthreads();
-    thr = __hip_atomic_load(a.thr_out + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by another block
+    thr = as_f32(atomicAdd(reinterpret_cast<unsigned*>(a.thr_out + pl), 0u));  // written by another block
     if (inactive) {
       zero_rows();
       return;
