@@ -230,18 +230,18 @@ def test_rbio31_float32_spread_of_the_reference_algorithm_itself():
     CPU: the oracle in both regimes."""
     import warnings
 
-    img = synth.synthetic_plane(3, 260, 331)
+    img = synth.synthetic_plane(3, 196, 251)
     spread = {}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for name in ("rbio3.1", "bior3.1", "rbio2.2", "db3", "sym8"):
+        for name in ("rbio3.1", "bior3.1", "db3"):
             bank = wavelets.filter_bank(name)
             a = orc.log_space_fft_filtering(img, wavelet=bank, level=None, sigma=128, max_threshold=12)
             b = orc.log_space_fft_filtering(img.astype(np.float32), wavelet=bank, level=None, sigma=128, max_threshold=12)
             r = np.abs(a - b) / np.abs(a)
             spread[name] = (float(r.max()), float(np.median(r)))
     assert spread["rbio3.1"][0] > 3e-4 and spread["rbio3.1"][1] > 4e-6, spread
-    for name in ("bior3.1", "rbio2.2", "db3", "sym8"):
+    for name in ("bior3.1", "db3"):
         assert spread[name][0] < 5e-5 and spread[name][1] < 4e-6, (name, spread)
 
 
