@@ -268,3 +268,16 @@ def test_gpu_chunk_map_on_a_production_style_blosc_store(tmp_path):
     assert json.load(open(os.path.join(out.path, ".zarray")))["compressor"]["cname"] == "zstd"
     frame = open(out._chunk_path((0, 0, 1, 2, 3)), "rb").read()
     assert frame[0] == 2 and (frame[2] >> 5) == ZSTD and struct.unpack("<I", frame[4:8])[0] == 8 * 32 * 32 * 2
+
+
+def test_mutated_frames_never_leave_their_buffers(tmp_path):
+    """The decoders of csrc/dsx_io.h (Blosc container, PNG scanline filters) take file contents: 20 000 random corruptions
+    and truncations of a good frame under AddressSanitizer / UBSan (host build; tests/host/codec_mutation_check.cpp)."""
+    import subprocess
+
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "codec_mutation_check.cpp")
+    exe = str(tmp_path / "codec_mutation_check")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-o", exe, src, "-lz", "-lpthread", "-ldl"], check=True, cwd=os.path.dirname(src))
+    out = subprocess.run([exe, "20000"], check=True, capture_output=True, text=True, cwd=os.path.dirname(src)).stdout
+    assert out.strip().endswith("ok") and "rejected" in out, out
