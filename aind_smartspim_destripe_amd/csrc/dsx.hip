@@ -1122,10 +1122,17 @@ int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, i
     if (p.L > 0) {
       std::vector<dsx::PlaneStats> hs((size_t)nb);
       DSX_HIP(hipMemcpy(hs.data(), ctx->d_stats, sizeof(dsx::PlaneStats) * nb, hipMemcpyDeviceToHost));
-      for (int k = 0; k < nb; ++k)
-        if (hs[(size_t)k].flags & 2ull)
-          return fail(ctx, DSX_EHIP, "plane " + std::to_string(start + k) + ": the plane barrier of the fused histogram / "
-                                     "row-filter kernel timed out (set DSX_FUSE_HIST=0)");
+      {
+        std::string late;
+        for (int k = 0; k < nb; ++k)
+          if (hs[(size_t)k].flags & 2ull)
+            late += " " + std::to_string(start + k) + "(" + std::to_string(hs[(size_t)k].arrive[0]) + "/" +
+                    std::to_string(hs[(size_t)k].arrive[1]) + ", ready " + std::to_string(hs[(size_t)k].ready[0]) +
+                    std::to_string(hs[(size_t)k].ready[1]) + ", tickets " + std::to_string(hs[0].ticket[0]) + ")";
+        if (!late.empty())
+          return fail(ctx, DSX_EHIP, "the plane barrier of the fused histogram / row-filter kernel timed out (set "
+                                     "DSX_FUSE_HIST=0); planes (blocks arrived at level 1 / 2):" + late);
+      }
       for (int k = 0; k < nb && in_dtype == DSX_F32; ++k)
         if (hs[(size_t)k].flags & 1ull)
           return fail(ctx, DSX_EVALUE, "plane " + std::to_string(start + k) +

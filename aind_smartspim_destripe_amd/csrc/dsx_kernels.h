@@ -1033,14 +1033,32 @@ __device__ __forceinline__ double otsu_from_hist(float q_lo, float q_hi, const u
   }
   wave_sync();
   if (lane < 2) {
+    // 256 dependent additions per running sum; what made this loop slow was not them but an LDS round trip per step
+    // (the stores of one step may alias the loads of the next as far as the compiler knows): 16 values are loaded back
+    // to back, summed in registers, stored back to back -- 18 -> 2 us for the one wave every block of a plane waits for
+    // in k_rowfilter<..., HIST>, and the same in k_otsu
     double w = 0.0, sacc = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < 256; ++k) {
-      const int g = lane ? 255 - k : k;
-      w += s_cnt[g];
-      sacc += s_cb[g];
-      s_w[lane][g] = w;
-      s_s[lane][g] = sacc;
+    for (int k0 = 0; k0 < 256; k0 += 16) {
+      double c[16], b[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int g = lane ? 255 - (k0 + j) : k0 + j;
+        c[j] = s_cnt[g];
+        b[j] = s_cb[g];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        w += c[j];
+        sacc += b[j];
+        c[j] = w;
+        b[j] = sacc;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int g = lane ? 255 - (k0 + j) : k0 + j;
+        s_w[lane][g] = c[j];
+        s_s[lane][g] = b[j];
+      }
     }
   }
   wave_sync();
@@ -1521,7 +1539,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
     if (last_block) {
       if (wave == 0) {
         double* scratch = (double*)(dsx_smem + M);  // 12 KB over the first FFT buffers
-        const double otsu = otsu_from_hist<true>(qmin, qmax, a.hist + pl * 256, scratch, lane);
+        const double otsu = (a.ablate & 8192) ? 1.0 : otsu_from_hist<true>(qmin, qmax, a.hist + pl * 256, scratch, lane);
         if (lane == 0) {
           const double t = fmin(otsu >= 0 ? sqrt(otsu) : 0.0, (double)a.max_thr[cfg]);
           atomicExch(reinterpret_cast<unsigned*>(a.otsu_out + pl), as_u32((float)otsu));
@@ -1530,13 +1548,13 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
           atomicExch(&ps->ready[a.sync_slot], 1u);
         }
       }
-    } else if (tid == 0) {
+    } else if (tid == 0 && !(a.ablate & 4096)) {
       // every block this one waits for holds a lower ticket and is running; the bound only guards against a
       // runtime that breaks that promise (~2 s), and is reported instead of hanging the device
       unsigned spins = 0;
       while (atomicAdd(&ps->ready[a.sync_slot], 0u) == 0u) {
-        __builtin_amdgcn_s_sleep(64);
-        if (++spins > (1u << 18)) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 20)) {
           atomicOr(&ps->flags, 2ull);
           break;
         }
