@@ -253,7 +253,9 @@ hipError_t launch_rowfilter(const dsx::RowArgs& a_in, int npairs, int nb, hipStr
   const size_t smem = (size_t)a_in.M * (wpb + 1) * sizeof(float2);
   dsx::RowArgs a = a_in;
   a.blocks_per_plane = (npairs + wpb - 1) / wpb;  // HIST: work items are handed out by ticket, plane by plane
+  a.n_planes = nb;
   dim3 grid(a.blocks_per_plane, nb);
+  if (HIST) grid = dim3(a.blocks_per_plane * nb + dsx::kHistSpareBlocks, 1);
   hipLaunchKernelGGL((dsx::k_rowfilter<CPL, GF, NT, HALO, PLAN, HIST>), grid, dim3(64 * wpb), smem, s, a);
   return hipGetLastError();
 }
@@ -1128,7 +1130,9 @@ int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, i
           if (hs[(size_t)k].flags & 2ull)
             late += " " + std::to_string(start + k) + "(" + std::to_string(hs[(size_t)k].arrive[0]) + "/" +
                     std::to_string(hs[(size_t)k].arrive[1]) + ", ready " + std::to_string(hs[(size_t)k].ready[0]) +
-                    std::to_string(hs[(size_t)k].ready[1]) + ", tickets " + std::to_string(hs[0].ticket[0]) + ")";
+                    std::to_string(hs[(size_t)k].ready[1]) + ", tickets " + std::to_string(hs[0].ticket[0]) +
+                    ", gave up: highest ticket " + std::to_string(hs[(size_t)k].pad1_[0]) + ", arrived by then at most " +
+                    std::to_string(hs[(size_t)k].pad1_[2]) + ")";
         if (!late.empty())
           return fail(ctx, DSX_EHIP, "the plane barrier of the fused histogram / row-filter kernel timed out (set "
                                      "DSX_FUSE_HIST=0); planes (blocks arrived at level 1 / 2):" + late);

@@ -1138,6 +1138,7 @@ struct RowArgs {
   float* otsu_out;         // [B][L]
   float max_thr[2];
   int blocks_per_plane;
+  int n_planes;            // work items = blocks_per_plane * n_planes; the launch carries kHistSpareBlocks more blocks
   int sync_slot;           // index into PlaneStats::arrive / ready / ticket (0: level 1, 1: level 2)
 };
 
@@ -1385,6 +1386,7 @@ template <int CPL>
 constexpr int row_waves_per_simd() {
   return CPL <= 18 ? 4 : 1;
 }
+constexpr int kHistSpareBlocks = 128;  // k_rowfilter<..., HIST>: spare workgroups per launch (16 per compute die)
 constexpr int kRowMaxWaves = 8;  // waves (row pairs) per block; they share one twiddle table
 
 // One wave per pair of rows.  CPL = complex values per lane = ceil(M / 64).
@@ -1410,11 +1412,18 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   // HIST: one word of block-wide exchange, 16 KB into the FFT buffers (behind the histogram / Otsu scratch; no static
   // LDS: the dynamic allocation may be the whole 160 KB)
   volatile int* s_item = (volatile int*)(dsx_smem + M + 2048);
-  int item_x = blockIdx.x, item_plane = blockIdx.y;
+  int item_x = blockIdx.x, item_plane = blockIdx.y, my_ticket = 0;
   if (HIST) {
     if (tid == 0) *s_item = (int)atomicAdd(&a.stats[0].ticket[a.sync_slot], 1u);
     __syncthreads();
     const int item = *s_item;
+    // Spare blocks.  Workgroup i of a launch is bound to compute die i mod 8, and the blocks that start last -- the
+    // ones that get the tickets of the LAST plane -- sit on whichever die was slowest: that die can end up full of
+    // blocks waiting at the last plane's barrier while the launch's remaining workgroups are bound to that very die
+    // (found as a barrier time-out of the last plane, one launch in four).  With spare workgroups on every die the
+    // remaining tickets are taken by whichever die has room; a block whose ticket is past the work returns at once.
+    if (item >= a.blocks_per_plane * a.n_planes) return;
+    my_ticket = item;
     item_plane = item / a.blocks_per_plane;
     item_x = item - item_plane * a.blocks_per_plane;
     __syncthreads();
@@ -1556,6 +1565,10 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1u << 20)) {
           atomicOr(&ps->flags, 2ull);
+          // diagnosis of the open issue: who gave up, and how many blocks of the plane had arrived by then
+          atomicMax(&ps->pad1_[0], (unsigned)my_ticket + 1u);
+          atomicMin(&ps->pad1_[1], atomicAdd(&ps->arrive[a.sync_slot], 0u) + 0x80000000u);
+          atomicMax(&ps->pad1_[2], atomicAdd(&ps->arrive[a.sync_slot], 0u));
           break;
         }
       }

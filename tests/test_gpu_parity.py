@@ -672,11 +672,9 @@ def test_fused_histogram_row_filter_is_bit_identical_to_the_separate_kernels(mon
     for an unsplit cohort (helper stream), a cohort split over the four streams, and a plane of constant rows (constant
     cH^2: no histogram at all).
 
-    The switch is an experiment (off by default) with an OPEN ISSUE: about one launch in four, the
-    barrier of the LAST plane of a launch does not complete within the kernel's bound (all 65 blocks have arrived, the flag
-    is up afterwards); the kernel reports it (PlaneStats::flags -> DsxError from the host-buffer call) instead of hanging.
-    A run that reports the time-out is repeated (up to 6 times); what is asserted is that every run that completes is
-    bit-identical."""
+    The switch is an experiment (off by default).  Before the launch carried spare workgroups the
+    barrier of the last plane of a launch ran into the kernel's bound about one launch in four (reported through
+    PlaneStats::flags -> DsxError, never a hang); a run that reports it is still repeated here, and the count printed."""
     h, w = 2048, 2048
     bank = synth.synthetic_bank(6, h, w)
     flatp = np.full((h, w), 300, np.uint16)  # cH == 0 everywhere: min == max at every level
