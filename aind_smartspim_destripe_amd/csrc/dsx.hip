@@ -85,11 +85,15 @@ struct dsx_ctx {
   bool wl_set = false;
   float wl[4][dsx::kMaxTaps] = {};       // dec_lo, dec_hi, rec_lo, rec_hi of the current plan
   float wl_bank[4][dsx::kMaxTaps] = {};  // ... of the last dsx_set_wavelet
-  // DSX_FUSE_HIST: bit mask of level indices whose histogram / Otsu step runs inside the row filter (k_rowfilter<...,
-  // HIST>).  OFF by default: bit-identical results, but the plane barrier costs more than the saved pass over cH
-  // (single stream 6.2 instead of 5.1 ms per 256 planes; four streams of 64 planes stall)
-  int fuse_hist = 0;
-  int ablate = 0;  // DSX_ABLATE environment variable: row-filter phase ablation, diagnosis only
+  // Sticky flag word in pinned host memory, written by k_otsu when a plane's PlaneStats::flags is set (a float32
+  // pixel whose log(1 + x) is not finite).  The asynchronous device-buffer path (dsx_run_device) cannot raise at
+  // the call; the next synchronising entry point (dsx_sync, dsx_event_sync, dsx_stream_sync, dsx_get_stats) reports
+  // DSX_EVALUE instead and clears the word.
+  unsigned* h_sticky = nullptr;
+  unsigned* d_sticky = nullptr;
+  // DSX_ABLATE environment variable (timing-only switches that return WRONG pixels): read only by a library built
+  // with -DDSX_DIAG (tools/build_variant.sh); the product build has no such switch
+  int ablate = 0;
   // sub-cohort streams: a cohort is split into parts that run their launch chains concurrently, so that
   // latency-bound (march) and compute-bound (row filter) kernels of different parts overlap on the chip
   static constexpr int kMaxStreams = 8;
@@ -237,13 +241,13 @@ int rowfilter_waves_per_block(int M) {
   return best_w;
 }
 
-template <int CPL, int GF = -1, int NT = -1, int HALO = -1, int PLAN = 0, bool HIST = false>
+template <int CPL, int GF = -1, int NT = -1, int HALO = -1, int PLAN = 0>
 hipError_t launch_rowfilter(const dsx::RowArgs& a_in, int npairs, int nb, hipStream_t s) {
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!attr_set[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)dsx::k_rowfilter<CPL, GF, NT, HALO, PLAN, HIST>,
+    hipError_t e = hipFuncSetAttribute((const void*)dsx::k_rowfilter<CPL, GF, NT, HALO, PLAN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev & 63] = true;
@@ -251,27 +255,13 @@ hipError_t launch_rowfilter(const dsx::RowArgs& a_in, int npairs, int nb, hipStr
   static const int force_wpb = getenv("DSX_ROW_WPB") ? atoi(getenv("DSX_ROW_WPB")) : 0;
   const int wpb = force_wpb ? force_wpb : ((CPL > 18) ? 4 : rowfilter_waves_per_block(a_in.M));
   const size_t smem = (size_t)a_in.M * (wpb + 1) * sizeof(float2);
-  dsx::RowArgs a = a_in;
-  a.blocks_per_plane = (npairs + wpb - 1) / wpb;  // HIST: work items are handed out by ticket, plane by plane
-  a.n_planes = nb;
-  dim3 grid(a.blocks_per_plane, nb);
-  if (HIST) grid = dim3(a.blocks_per_plane * nb + dsx::kHistSpareBlocks, 1);
-  hipLaunchKernelGGL((dsx::k_rowfilter<CPL, GF, NT, HALO, PLAN, HIST>), grid, dim3(64 * wpb), smem, s, a);
+  const dsx::RowArgs& a = a_in;
+  const dim3 grid((npairs + wpb - 1) / wpb, nb);
+  hipLaunchKernelGGL((dsx::k_rowfilter<CPL, GF, NT, HALO, PLAN>), grid, dim3(64 * wpb), smem, s, a);
   return hipGetLastError();
 }
 
-// Does the instantiation this level takes have the fused histogram / Otsu variant (k_rowfilter<..., HIST = true>)?
-bool rowfilter_has_hist(const dsx::LevelPlan& lp) {
-  const int gf = lp.w >> 8, nt = (lp.w - (gf << 8) + 63) >> 6;
-  auto plan_is = [&](int m, int r0, int r1, int r2) {
-    return lp.M == m && lp.npass == 3 && lp.radix[0] == r0 && lp.radix[1] == r1 && lp.radix[2] == r2;
-  };
-  if (gf == 4 && nt == 1 && lp.K == 0 && plan_is(1026, 19, 9, 6)) return true;   // level 1 of a 2048-wide plane
-  if (gf == 2 && nt == 1 && lp.K > 0 && plan_is(1071, 17, 9, 7)) return true;    // level 2 of a 2048-wide plane
-  return false;
-}
-
-hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s, bool hist = false) {
+hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s) {
   const int cpl = (a.M + 63) / 64;
   // slot structure of the row (full 256-value groups, 64-value tail slots) and pass list: the wide levels of
   // 2048-, 2000- and 1800-wide planes have instantiations with all of it as compile-time constants
@@ -286,12 +276,12 @@ hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStre
   if (cpl <= 18) {
     if (gf == 4 && nt == 1 && a.K == 0) {
       if (plan_is(1026, 19, 9, 6))
-        return hist ? launch_rowfilter<18, 4, 1, 0, 1, true>(a, npairs, nb, s) : launch_rowfilter<18, 4, 1, 0, 1>(a, npairs, nb, s);
+        return launch_rowfilter<18, 4, 1, 0, 1>(a, npairs, nb, s);
       return launch_rowfilter<18, 4, 1, 0>(a, npairs, nb, s);
     }
     if (gf == 2 && nt == 1 && a.K > 0) {
       if (plan_is(1071, 17, 9, 7))
-        return hist ? launch_rowfilter<18, 2, 1, 1, 2, true>(a, npairs, nb, s) : launch_rowfilter<18, 2, 1, 1, 2>(a, npairs, nb, s);
+        return launch_rowfilter<18, 2, 1, 1, 2>(a, npairs, nb, s);
       return launch_rowfilter<18, 2, 1, 1>(a, npairs, nb, s);
     }
     if (gf == 1 && nt == 4 && a.K > 0) {
@@ -361,21 +351,18 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   // their histograms (and, below, their row filters) run on the part's helper stream BESIDE the coarse
   // levels' launches instead of after them.
   const bool split = v.helper != nullptr && fuse12 && L >= 3;
-  // DSX_SKIP_HIST / DSX_SKIP_ROW: bit masks of level indices whose histogram / row-filter launch is left out
-  // (diagnosis only, results are wrong): what the chain would gain if that kernel were free
+  // DSX_SKIP_HIST / DSX_SKIP_ROW: bit masks of level indices whose histogram / row-filter launch is left out, and
+  // DSX_SKIP_COARSE=k: no launch for levels with index >= k (what the chain would gain if those kernels were free).
+  // The results are WRONG: the switches only exist in a -DDSX_DIAG build.
+#ifdef DSX_DIAG
   static const int skip_hist = getenv("DSX_SKIP_HIST") ? atoi(getenv("DSX_SKIP_HIST")) : 0;
   static const int skip_row = getenv("DSX_SKIP_ROW") ? atoi(getenv("DSX_SKIP_ROW")) : 0;
-  // Levels 1 / 2 of the hot shapes: histogram + Otsu inside the row-filter kernel (k_rowfilter<..., HIST = true>), no
-  // separate pass over cH.  DSX_FUSE_HIST = bit mask of level indices (default 0 = off, see dsx_ctx::fuse_hist); the
-  // staged debug runs (dsx_set_stop_after) and profiling keep the separate kernels.
-  const int fuse_hist_env = ctx->fuse_hist;
-  int fused_levels = 0;
-  if (!generic && !ctx->profiling && ctx->stop_after == 0)
-    for (int l = 0; l < L && l < 2; ++l)
-      if (((fuse_hist_env >> l) & 1) && rowfilter_has_hist(p.lv[l])) fused_levels |= 1 << l;
+  static const int skip_from = getenv("DSX_SKIP_COARSE") ? atoi(getenv("DSX_SKIP_COARSE")) : 1000;
+#else
+  constexpr int skip_hist = 0, skip_row = 0, skip_from = 1000;
+#endif
   auto hist_level = [&](int l, hipStream_t hs) -> int {
     if ((skip_hist >> l) & 1) return DSX_OK;
-    if ((fused_levels >> l) & 1) return DSX_OK;
     const dsx::LevelPlan& lp = p.lv[l];
     dsx::HistArgs a;
     a.ws = v.ws;
@@ -393,9 +380,6 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     DSX_HIP(hipGetLastError());
     return DSX_OK;
   };
-  // DSX_SKIP_COARSE=k (diagnosis only, results are wrong): no launch for levels with index >= k -- the
-  // time the chain would take if the coarse levels were free
-  static const int skip_from = getenv("DSX_SKIP_COARSE") ? atoi(getenv("DSX_SKIP_COARSE")) : 1000;
   for (int l = 0; l < L; ++l) {
     if (fuse12 && l == 1) continue;
     if (l >= skip_from) continue;
@@ -500,7 +484,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.max_thr[0] = (float)ctx->cfg[0].max_threshold;
     a.max_thr[1] = (float)ctx->cfg[1].max_threshold;
     a.L = L;
-    a.fused_levels = fused_levels;
+    a.sticky = ctx->d_sticky;
     LaunchScope ls(ctx, KC_OTSU);
     hipLaunchKernelGGL(dsx::k_otsu, dim3(L, nb), dim3(64), 0, s, a);
     DSX_HIP(hipGetLastError());
@@ -544,20 +528,9 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.kcut[1] = lp.kcut[1];
     a.inv_M = 1.0f / (float)lp.M;
     a.ablate = ctx->ablate;
-    const bool hist_here = ((fused_levels >> l) & 1) != 0;
-    if (hist_here) {
-      a.minmax = v.minmax;
-      a.hist = v.hist;
-      a.stats = v.stats;
-      a.thr_out = v.thr;
-      a.otsu_out = v.otsu;
-      a.max_thr[0] = (float)ctx->cfg[0].max_threshold;
-      a.max_thr[1] = (float)ctx->cfg[1].max_threshold;
-      a.sync_slot = l;
-    }
     const int npairs = (lp.h + 1) / 2;
     LaunchScope ls(ctx, KC_ROW);
-    DSX_HIP(dispatch_rowfilter(a, npairs, nb, rs, hist_here));
+    DSX_HIP(dispatch_rowfilter(a, npairs, nb, rs));
   }
   if (split_inv) DSX_HIP(hipEventRecord(v.ev[3], v.helper));
   if (ctx->stop_after == 2) return DSX_OK;
@@ -800,6 +773,17 @@ int run_cohort_split(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void*
   return DSX_OK;
 }
 
+// Value errors of planes that went through the asynchronous device-buffer path (see dsx_ctx::h_sticky): reported once,
+// by the first synchronising entry point after the kernels that found them.
+int check_sticky(dsx_ctx* ctx) {
+  if (!ctx->h_sticky) return DSX_OK;
+  const unsigned f = *(volatile unsigned*)ctx->h_sticky;
+  if (f == 0u) return DSX_OK;
+  *(volatile unsigned*)ctx->h_sticky = 0u;
+  return fail(ctx, DSX_EVALUE, "a plane of an earlier dsx_run_device call: autodetected range of [nan, nan] is not finite "
+                               "(a float32 pixel is NaN, infinite or <= -1); that plane's result is not valid");
+}
+
 }  // namespace
 
 extern "C" {
@@ -826,9 +810,10 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
   if (e != hipSuccess) { g_init_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return DSX_EHIP; }
   dsx_ctx* c = new dsx_ctx();
   c->device = device;
+#ifdef DSX_DIAG
   if (const char* ab = getenv("DSX_ABLATE")) c->ablate = atoi(ab);
+#endif
   if (const char* gm = getenv("DSX_GRAPH")) c->graph_mode = atoi(gm) != 0 ? 1 : 0;
-  if (const char* fh = getenv("DSX_FUSE_HIST")) c->fuse_hist = atoi(fh);
   if (const char* ns = getenv("DSX_STREAMS")) c->n_streams = std::max(1, std::min(atoi(ns), (int)dsx_ctx::kMaxStreams));
   // DSX_PRIO=p0,p1,...: stream priority per sub-cohort stream (experiment hook; default: all equal)
   int prio[dsx_ctx::kMaxStreams] = {};
@@ -854,6 +839,11 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_xs, hipEventDisableTiming);
   for (int i = 0; i < dsx_ctx::kEventSlots && e == hipSuccess; ++i)
     e = hipEventCreateWithFlags(&c->ev_slot[i], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_sticky, 64, hipHostMallocMapped);
+  if (e == hipSuccess) {
+    *c->h_sticky = 0u;
+    e = hipHostGetDevicePointer((void**)&c->d_sticky, c->h_sticky, 0);
+  }
   if (e == hipSuccess) e = hipEventCreate(&c->t0);
   if (e == hipSuccess) e = hipEventCreate(&c->t1);
   if (e != hipSuccess) {
@@ -885,6 +875,7 @@ void dsx_destroy(dsx_ctx* ctx) {
   }
   for (int i = 0; i < 2; ++i)
     if (ctx->copy_stream[i]) { (void)hipStreamSynchronize(ctx->copy_stream[i]); (void)hipStreamDestroy(ctx->copy_stream[i]); }
+  if (ctx->h_sticky) (void)hipHostFree(ctx->h_sticky);
   if (ctx->ev_xs) (void)hipEventDestroy(ctx->ev_xs);
   for (int i = 0; i < dsx_ctx::kEventSlots; ++i)
     if (ctx->ev_slot[i]) (void)hipEventDestroy(ctx->ev_slot[i]);
@@ -1075,7 +1066,7 @@ int dsx_sync(dsx_ctx* ctx) {
   if (!ctx) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
   DSX_HIP(hipStreamSynchronize(use_main(ctx)));
-  return DSX_OK;
+  return check_sticky(ctx);
 }
 
 int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, int out_dtype,
@@ -1124,19 +1115,7 @@ int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, i
     if (p.L > 0) {
       std::vector<dsx::PlaneStats> hs((size_t)nb);
       DSX_HIP(hipMemcpy(hs.data(), ctx->d_stats, sizeof(dsx::PlaneStats) * nb, hipMemcpyDeviceToHost));
-      {
-        std::string late;
-        for (int k = 0; k < nb; ++k)
-          if (hs[(size_t)k].flags & 2ull)
-            late += " " + std::to_string(start + k) + "(" + std::to_string(hs[(size_t)k].arrive[0]) + "/" +
-                    std::to_string(hs[(size_t)k].arrive[1]) + ", ready " + std::to_string(hs[(size_t)k].ready[0]) +
-                    std::to_string(hs[(size_t)k].ready[1]) + ", tickets " + std::to_string(hs[0].ticket[0]) +
-                    ", gave up: highest ticket " + std::to_string(hs[(size_t)k].pad1_[0]) + ", arrived by then at most " +
-                    std::to_string(hs[(size_t)k].pad1_[2]) + ")";
-        if (!late.empty())
-          return fail(ctx, DSX_EHIP, "the plane barrier of the fused histogram / row-filter kernel timed out (set "
-                                     "DSX_FUSE_HIST=0); planes (blocks arrived at level 1 / 2):" + late);
-      }
+      if (ctx->h_sticky) *ctx->h_sticky = 0u;  // reported right here, per plane
       for (int k = 0; k < nb && in_dtype == DSX_F32; ++k)
         if (hs[(size_t)k].flags & 1ull)
           return fail(ctx, DSX_EVALUE, "plane " + std::to_string(start + k) +
@@ -1234,13 +1213,13 @@ int dsx_event_sync(dsx_ctx* ctx, int slot) {
   if (!ctx || slot < 0 || slot >= dsx_ctx::kEventSlots) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
   DSX_HIP(hipEventSynchronize(ctx->ev_slot[slot]));
-  return DSX_OK;
+  return check_sticky(ctx);
 }
 int dsx_stream_sync(dsx_ctx* ctx, int stream_id) {
   if (!ctx || !stream_id_ok(stream_id)) return DSX_EINVAL;
   DSX_HIP(hipSetDevice(ctx->device));
   DSX_HIP(hipStreamSynchronize(pick_stream(ctx, stream_id)));
-  return DSX_OK;
+  return check_sticky(ctx);
 }
 int dsx_timer_start(dsx_ctx* ctx) {
   if (!ctx) return DSX_EINVAL;
@@ -1575,6 +1554,7 @@ int dsx_get_stats(dsx_ctx* ctx, int plane, double* fore_mean, double* back_mean,
   if (plane < 0 || plane >= ctx->last_n) return fail(ctx, DSX_EINVAL, "plane index outside the last cohort");
   DSX_HIP(hipSetDevice(ctx->device));
   DSX_HIP(hipStreamSynchronize(use_main(ctx)));
+  if (int rc = check_sticky(ctx)) return rc;
   double m[2];
   int c = 0;
   DSX_HIP(hipMemcpy(m, ctx->d_means + 2 * plane, sizeof(m), hipMemcpyDeviceToHost));

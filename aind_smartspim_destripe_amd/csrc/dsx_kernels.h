@@ -41,6 +41,14 @@
 #endif
 
 
+// Timing-only switches (DSX_ABLATE bits: kernels skip a phase or a store path and return WRONG pixels) exist in
+// -DDSX_DIAG builds only (tools/build_variant.sh); in the product build the tests fold to `false`.
+#ifdef DSX_DIAG
+#define DSX_ABL(a, bits) (((a).ablate & (bits)) != 0)
+#else
+#define DSX_ABL(a, bits) false
+#endif
+
 namespace dsx {
 
 constexpr int kMaxLevels = 16;
@@ -94,16 +102,10 @@ struct PlaneStats {
   double sum_all;              // sum of all pixels
   unsigned long long cnt_fg;   // pixels in the foreground class
   // bit 0: a float32 pixel was NaN, infinite or <= -1 (log(1 + x) is not finite: the reference dies in
-  // numpy.histogram, filtering.py:188 -> skimage threshold_otsu); dsx_run_host turns it into DSX_EVALUE
-  // bit 1: the plane barrier of the fused histogram / row-filter kernel timed out (k_rowfilter<..., HIST>)
+  // numpy.histogram, filtering.py:188 -> skimage threshold_otsu); dsx_run_host turns it into DSX_EVALUE, the
+  // device-buffer entry points fold it into the context's sticky flag word (k_otsu), read by dsx_sync & co.
   unsigned long long flags;
-  // k_rowfilter<..., HIST = true> (levels 1, 2): blocks of a plane that have added their part of the histogram; set
-  // once the last of them has written the level's Otsu threshold; next work item of the launch (first plane of a part)
-  unsigned arrive[2], ticket[2];
-  unsigned pad0_[20];
-  // polled by the waiting blocks (plain loads): on a cache line of its own, away from the counters above
-  unsigned ready[2];
-  unsigned pad1_[30];
+  unsigned pad_[56];
 };
 static_assert(sizeof(PlaneStats) == 256, "control block layout");
 
@@ -498,7 +500,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   const bool c_s1 = EDGE ? (FUSE && out_lane && jl + 1 >= fg.own1_lo && jl + 1 < fg.own1_hi) : c_s0;
   // DSX_ABLATE bit 64 (diagnosis, wrong results): every strip's da_1 row piece starts on a 512-byte boundary of the
   // row -- what the store path would gain from aligned strip boundaries (they sit at multiples of 488 bytes)
-  const unsigned off_da = (unsigned)max(jl, 0) * 4u + ((FUSE && (a.ablate & 64)) ? 24u * (unsigned)strip : 0u);
+  const unsigned off_da = (unsigned)max(jl, 0) * 4u + ((FUSE && DSX_ABL(a, 64)) ? 24u * (unsigned)strip : 0u);
   const int jo2 = fg.o2 + lane;                              // level-2 column of this lane
   const bool l2_valid = FUSE && lane < kFuseOut && (!EDGE || jo2 < a.w2);
   const bool l2_store = l2_valid && jo2 >= fg.own2_lo;
@@ -551,7 +553,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     const float q = v.y * v.y;
     q2min = fminf(q2min, l2_valid ? q : __builtin_huge_valf());
     q2max = fmaxf(q2max, l2_valid ? q : 0.f);
-    if (l2_store && !(a.ablate & (16 | 128))) {  // 128: diagnosis, only the level-2 stores are left out
+    if (l2_store && !DSX_ABL(a, 16 | 128)) {  // 128: diagnosis, only the level-2 stores are left out
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rs_aa2, off_2, (unsigned)(i2 * a.lda2) * 4u, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rs_da2, off_2, (unsigned)(i2 * a.ld2) * 4u, 0);
       if (l2_edge) {  // extension margins of aa_2, read by the next level's aligned vector loads
@@ -646,9 +648,9 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
       if (out_lane) {
         const int j = jl;
         const float q0 = res[1][0] * res[1][0], q1 = res[1][1] * res[1][1];
-        if (own_row && !(a.ablate & (16 | 256))) {  // (256: diagnosis, only the da_1 stores are left out)  da_1: owned rows and columns only (overlap rows / columns belong to a neighbour)
+        if (own_row && !DSX_ABL(a, 16 | 256)) {  // (256: diagnosis, only the da_1 stores are left out)  da_1: owned rows and columns only (overlap rows / columns belong to a neighbour)
           // (64: diagnosis, with the 512-byte strip pieces above: a row pitch of 33 cache lines -- no partial line at all)
-          const unsigned soff = (a.ablate & 64) ? (unsigned)i * 4224u : (unsigned)(i * a.ld) * 4u;
+          const unsigned soff = DSX_ABL(a, 64) ? (unsigned)i * 4224u : (unsigned)(i * a.ld) * 4u;
           constexpr int aux = DSX_NT ? kBufNT : 0;
           if (c_s0 && c_s1) {
             const dsx_u32x2 dv = {__float_as_uint(res[1][0]), __float_as_uint(res[1][1])};
@@ -997,15 +999,11 @@ struct OtsuArgs {
   double* means; // [B][2]
   float max_thr[2];
   int L;
-  int fused_levels;  // bit l: level index l takes its threshold from the fused histogram / row-filter kernel
+  unsigned* sticky;  // host-mapped flag word of the context (dsx_ctx::h_sticky), may be null
 };
 
 // Otsu value of one plane and level from its 256-bin histogram, by ONE wave (64 lanes): returns the value on every
 // lane.  scratch: 6 x 256 doubles of LDS.  The caller applies sqrt / the threshold cap.
-// COHERENT: the counts were made by atomics of other blocks of the SAME kernel (k_rowfilter<..., HIST>): read them with
-// read-modify-write atomics (performed where the other dies' atomics were) instead of fencing the whole L2.  (Device-
-// scope atomic LOADS are not enough on this chip: a line once loaded into the die's L2 keeps answering them.)
-template <bool COHERENT = false>
 __device__ __forceinline__ double otsu_from_hist(float q_lo, float q_hi, const unsigned* h, double* scratch, int lane) {
   // The class statistics are accumulated sequentially in numpy's order (cumsum forward for class 1,
   // cumsum over the reversed arrays for class 2): empty bins then give bit-identical variances on both
@@ -1027,7 +1025,7 @@ __device__ __forceinline__ double otsu_from_hist(float q_lo, float q_hi, const u
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int g = lane + 64 * i;
-    const double c = COHERENT ? (double)atomicAdd(const_cast<unsigned*>(h) + g, 0u) : (double)h[g];
+    const double c = (double)h[g];
     s_cnt[g] = c;
     s_cb[g] = c * (double)centre(g);
   }
@@ -1035,8 +1033,7 @@ __device__ __forceinline__ double otsu_from_hist(float q_lo, float q_hi, const u
   if (lane < 2) {
     // 256 dependent additions per running sum; what made this loop slow was not them but an LDS round trip per step
     // (the stores of one step may alias the loads of the next as far as the compiler knows): 16 values are loaded back
-    // to back, summed in registers, stored back to back -- 18 -> 2 us for the one wave every block of a plane waits for
-    // in k_rowfilter<..., HIST>, and the same in k_otsu
+    // to back, summed in registers, stored back to back -- 18 -> 2 us per plane and level
     double w = 0.0, sacc = 0.0;
     for (int k0 = 0; k0 < 256; k0 += 16) {
       double c[16], b[16];
@@ -1092,11 +1089,12 @@ __global__ __launch_bounds__(64) void k_otsu(OtsuArgs a) {
   const double back = cnt_bg > 0 ? (st.sum_all - st.sum_fg) / cnt_bg : 0.0;
   const int cfg = (fore > back && fore > a.high_int) ? 1 : 0;
   if (lvl == 0 && lane == 0) {
+    // (same value from every writer: a plain store, no read-modify-write across the host link)
+    if (st.flags != 0ull && a.sticky != nullptr) *(volatile unsigned*)a.sticky = 1u;
     a.cfg[plane] = cfg;
     a.means[2 * plane] = fore;
     a.means[2 * plane + 1] = back;
   }
-  if ((a.fused_levels >> lvl) & 1) return;  // this level's threshold comes out of k_rowfilter<..., HIST = true>
   const long long pl = (long long)plane * a.L + lvl;
   const unsigned* mm = a.minmax + pl * 2;
   const float q_lo = as_f32(~mm[0]), q_hi = as_f32(mm[1]);
@@ -1129,17 +1127,6 @@ struct RowArgs {
   int kcut[2];         // per config: the gains vanish for kcut < k < M - kcut
   float inv_M;
   int ablate;          // diagnosis only (DSX_ABLATE): 1 = no median, 2 = no FFT passes, 4 = no spectral step
-  // HIST (k_rowfilter<..., HIST = true>): the level's histogram, Otsu value and threshold are made HERE, from the rows
-  // the waves hold anyway -- the separate histogram pass over cH (4.2 MB per plane at level 1) goes away
-  const unsigned* minmax;  // [B][L][2]
-  unsigned* hist;          // [B][L][256]
-  PlaneStats* stats;       // [B]: arrive / ready / ticket words, flags
-  float* thr_out;          // [B][L]
-  float* otsu_out;         // [B][L]
-  float max_thr[2];
-  int blocks_per_plane;
-  int n_planes;            // work items = blocks_per_plane * n_planes; the launch carries kHistSpareBlocks more blocks
-  int sync_slot;           // index into PlaneStats::arrive / ready / ticket (0: level 1, 1: level 2)
 };
 
 __device__ __forceinline__ unsigned f32_key(float v) {
@@ -1386,7 +1373,6 @@ template <int CPL>
 constexpr int row_waves_per_simd() {
   return CPL <= 18 ? 4 : 1;
 }
-constexpr int kHistSpareBlocks = 128;  // k_rowfilter<..., HIST>: spare workgroups per launch (16 per compute die)
 constexpr int kRowMaxWaves = 8;  // waves (row pairs) per block; they share one twiddle table
 
 // One wave per pair of rows.  CPL = complex values per lane = ceil(M / 64).
@@ -1394,13 +1380,7 @@ constexpr int kRowMaxWaves = 8;  // waves (row pairs) per block; they share one 
 // (the hot shapes get their own instantiation without the per-group guards); -1: taken from a.w.
 // HALO_: 0 = direct transform (K == 0), 1 = periodic halo (K > 0), -1 = decided at run time.
 // PLAN_: compile-time FFT plan (StaticFft), 0 = the pass list of RowArgs.
-// HIST: the kernel also makes the level's histogram, Otsu value and threshold (see RowArgs).  Every block adds the
-// values of its rows to the plane's histogram, then the blocks of a plane meet at a barrier in global memory; the last
-// one to arrive computes the Otsu threshold and releases the others, which have kept their rows in registers.  Work
-// items are handed out by a ticket counter, plane by plane, so every block a waiting block depends on has a LOWER
-// ticket, i.e. is already running (or done): no deadlock whatever the dispatch order, and at most the blocks of one
-// incomplete plane per launch wait for slots.  The wait is bounded all the same (PlaneStats::flags bit 1).
-template <int CPL, int GF_ = -1, int NT_ = -1, int HALO_ = -1, int PLAN_ = 0, bool HIST = false>
+template <int CPL, int GF_ = -1, int NT_ = -1, int HALO_ = -1, int PLAN_ = 0>
 __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void k_rowfilter(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1409,29 +1389,10 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   const bool halo = (HALO_ >= 0) ? (HALO_ != 0) : (K > 0);
   float2* s_tw = dsx_smem;
   float2* buf = dsx_smem + (long long)M * (1 + wave);
-  // HIST: one word of block-wide exchange, 16 KB into the FFT buffers (behind the histogram / Otsu scratch; no static
-  // LDS: the dynamic allocation may be the whole 160 KB)
-  volatile int* s_item = (volatile int*)(dsx_smem + M + 2048);
-  int item_x = blockIdx.x, item_plane = blockIdx.y, my_ticket = 0;
-  if (HIST) {
-    if (tid == 0) *s_item = (int)atomicAdd(&a.stats[0].ticket[a.sync_slot], 1u);
-    __syncthreads();
-    const int item = *s_item;
-    // Spare blocks.  Workgroup i of a launch is bound to compute die i mod 8, and the blocks that start last -- the
-    // ones that get the tickets of the LAST plane -- sit on whichever die was slowest: that die can end up full of
-    // blocks waiting at the last plane's barrier while the launch's remaining workgroups are bound to that very die
-    // (found as a barrier time-out of the last plane, one launch in four).  With spare workgroups on every die the
-    // remaining tickets are taken by whichever die has room; a block whose ticket is past the work returns at once.
-    if (item >= a.blocks_per_plane * a.n_planes) return;
-    my_ticket = item;
-    item_plane = item / a.blocks_per_plane;
-    item_x = item - item_plane * a.blocks_per_plane;
-    __syncthreads();
-  }
-  const int pair = item_x * (blockDim.x >> 6) + wave;
+  const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
   const int npairs = (a.h + 1) >> 1;
   const bool live = pair < npairs;  // (waves past the last pair still help loading the twiddles)
-  const int plane = item_plane;
+  const int plane = blockIdx.y;
   const int r0 = live ? 2 * pair : 0;
   const bool has_b = (r0 + 1) < a.h;
   const int cfg = a.cfg[plane];
@@ -1455,12 +1416,11 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
       }
     }
   };
-  if (!HIST && inactive) {
+  if (inactive) {
     zero_rows();
     return;
   }
-  float thr = 0.f;
-  if (!HIST) thr = a.thr[(long long)plane * a.L + a.lvl];
+  const float thr = a.thr[(long long)plane * a.L + a.lvl];
 
   // ---- load both rows; background = masked entries zeroed (filtering.py:195-197) -------------
   // issue the row loads, THEN stage the twiddles: the two global latencies overlap
@@ -1485,101 +1445,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
     }
   }
   for (int i = tid; i < M; i += blockDim.x) s_tw[i] = a.tw[i];
-  __syncthreads();  // the only block-wide barrier (without HIST): afterwards every wave works on its own rows
-  if (HIST) {
-    // ---- histogram of q = cH^2 over the rows of this block (numpy rule, HistBins), into the plane's 256 bins ----
-    const long long pl = (long long)plane * a.L + a.lvl;
-    const unsigned* mm = a.minmax + pl * 2;
-    const float qmin = as_f32(~mm[0]), qmax = as_f32(mm[1]);
-    unsigned* s_h = (unsigned*)(dsx_smem + M);  // the waves' FFT buffers are not in use yet
-    PlaneStats* ps = a.stats + plane;
-    if (qmin < qmax) {  // (constant cH^2: no histogram, Otsu returns the value)
-      if (tid < 256) s_h[tid] = 0;
-      __syncthreads();
-      if (live) {
-        const HistBins bin_of(qmin, qmax);
-        // the four lowest bins hold most of the mass: byte-packed per-lane counters (at most 2 x 36 values per lane)
-        unsigned packed = 0;
-        auto count = [&](float x) {
-          const int idx = bin_of(x * x);
-          packed += (idx < 4) ? (1u << (8 * idx)) : 0u;
-          if (idx >= 4) atomicAdd(&s_h[idx], 1u);
-        };
-#pragma unroll
-        for (int g = 0; g < GV; ++g) {
-          if (g < gf) {
-            count(ra4[g].x); count(ra4[g].y); count(ra4[g].z); count(ra4[g].w);
-            if (has_b) { count(rb4[g].x); count(rb4[g].y); count(rb4[g].z); count(rb4[g].w); }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (k < nt && tn + 64 * k < N) {
-            count(rta[k]);
-            if (has_b) count(rtb[k]);
-          }
-        }
-        const unsigned c0 = __reduce_add_sync(~0ull, packed & 0xFFu), c1 = __reduce_add_sync(~0ull, (packed >> 8) & 0xFFu);
-        const unsigned c2 = __reduce_add_sync(~0ull, (packed >> 16) & 0xFFu), c3 = __reduce_add_sync(~0ull, packed >> 24);
-        if (lane == 0) {
-          if (c0) atomicAdd(&s_h[0], c0);
-          if (c1) atomicAdd(&s_h[1], c1);
-          if (c2) atomicAdd(&s_h[2], c2);
-          if (c3) atomicAdd(&s_h[3], c3);
-        }
-      }
-      __syncthreads();
-      if (tid < 256) {
-        const unsigned n = s_h[tid];
-        if (n) atomicAdd(&a.hist[pl * 256 + tid], n);
-      }
-    }
-    // ---- plane barrier: the last block to arrive turns the histogram into the threshold ----
-    // Everything that crosses blocks here is a device-scope read-modify-write atomic (performed past the compute die's
-    // L2), ordered by waiting for its completion -- NOT by agent-scope fences, which write back and invalidate the whole
-    // L2 of the die every time (measured: 3 x slower chain, other streams' kernels included), and not by atomic loads
-    // / stores either: polled with device-scope atomic loads the flag below was now and then never seen (a stale line
-    // in the die's L2 keeps answering; found by the test suite as a barrier time-out).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's histogram atomics are complete
-    __syncthreads();
-    if (tid == 0) *s_item = (atomicAdd(&ps->arrive[a.sync_slot], 1u) == (unsigned)a.blocks_per_plane - 1u) ? 1 : 0;
-    __syncthreads();
-    const bool last_block = *s_item != 0;  // block-uniform
-    if (last_block) {
-      if (wave == 0) {
-        double* scratch = (double*)(dsx_smem + M);  // 12 KB over the first FFT buffers
-        const double otsu = (a.ablate & 8192) ? 1.0 : otsu_from_hist<true>(qmin, qmax, a.hist + pl * 256, scratch, lane);
-        if (lane == 0) {
-          const double t = fmin(otsu >= 0 ? sqrt(otsu) : 0.0, (double)a.max_thr[cfg]);
-          atomicExch(reinterpret_cast<unsigned*>(a.otsu_out + pl), as_u32((float)otsu));
-          atomicExch(reinterpret_cast<unsigned*>(a.thr_out + pl), as_u32((float)t));
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // both are complete before the flag goes up
-          atomicExch(&ps->ready[a.sync_slot], 1u);
-        }
-      }
-    } else if (tid == 0 && !(a.ablate & 4096)) {
-      // every block this one waits for holds a lower ticket and is running; the bound only guards against a
-      // runtime that breaks that promise (~2 s), and is reported instead of hanging the device
-      unsigned spins = 0;
-      while (atomicAdd(&ps->ready[a.sync_slot], 0u) == 0u) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 20)) {
-          atomicOr(&ps->flags, 2ull);
-          // diagnosis of the open issue: who gave up, and how many blocks of the plane had arrived by then
-          atomicMax(&ps->pad1_[0], (unsigned)my_ticket + 1u);
-          atomicMin(&ps->pad1_[1], atomicAdd(&ps->arrive[a.sync_slot], 0u) + 0x80000000u);
-          atomicMax(&ps->pad1_[2], atomicAdd(&ps->arrive[a.sync_slot], 0u));
-          break;
-        }
-      }
-    }
-    __syncthreads();
-    thr = as_f32(atomicAdd(reinterpret_cast<unsigned*>(a.thr_out + pl), 0u));  // written by another block
-    if (inactive) {
-      zero_rows();
-      return;
-    }
-  }
+  __syncthreads();  // the only block-wide barrier: afterwards every wave works on its own rows
   if (!live) return;
 
   // Background values (masked entries zeroed, filtering.py:195-197) stay in registers as floats; slots past
@@ -1622,7 +1488,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   float meda = 0.f, medb = 0.f;
   // the medians only enter through the masked positions: skip them for a mask-free pair of rows
   const bool any_mask = __ballot((maska | maskb) != (mask_t)0) != 0ull;
-  if (any_mask && !(a.ablate & 1)) {
+  if (any_mask && !DSX_ABL(a, 1)) {
     const unsigned k1 = (unsigned)(N - 1) >> 1;
     const bool even = (N & 1) == 0;
     auto count2 = [&](float ta, float tb, bool le) -> unsigned {  // (#a < ta) | (#b < tb) << 16, wave totals
@@ -1739,7 +1605,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   }
   wave_sync();
 
-  if (!(a.ablate & 2)) {
+  if (!DSX_ABL(a, 2)) {
     if constexpr (PLAN_ > 0) StaticFft<PLAN_>::template run<CPL>(buf, s_tw, lane);
     else fft_run<CPL>(buf, s_tw, a, lane);
   }
@@ -1747,7 +1613,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   // ---- V[k] = G1[k] U[k] + G2[k] U[M - k], in place on the pair (k, M - k) ---------------------
   // G1 is real and even, G2[M - k] = conj(G2[k]) (both modes, dsx_plan.h).  The result is stored
   // re/im-swapped: the inverse transform runs through the forward passes.
-  if (!(a.ablate & 4)) {
+  if (!DSX_ABL(a, 4)) {
     const float2* g1 = a.g[cfg];
     const float2* g2 = g1 + M;
     const int kcut = a.kcut[cfg];
@@ -1766,7 +1632,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
     wave_sync();
   }
 
-  if (!(a.ablate & 2)) {
+  if (!DSX_ABL(a, 2)) {
     if constexpr (PLAN_ > 0) StaticFft<PLAN_>::template run_inverse<CPL>(buf, s_tw, lane, a.kcut[cfg]);
     else fft_run<CPL>(buf, s_tw, a, lane);
   }
@@ -2181,7 +2047,7 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
       return;
     }
     const long long o = plane * a.out_plane_stride + (long long)gy * a.wout + x0;
-    if (a.ablate & 32) {
+    if (DSX_ABL(a, 32)) {
       if (r[0] + r[1] + r[2] + r[3] == -12345.f) ((float*)a.out)[0] = 0.f;  // keeps the arithmetic alive
     } else if (a.out_dtype == 0) {
       if (vec_out) {
@@ -2230,7 +2096,7 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
       FinalRawI<IN_KIND> r0 = ri0, r1 = ri0;
       r0.u = odd_lane ? make_uint2(gx, gyv) : make_uint2(ri0.q.x, ri0.q.y);      // row 2p, own 4 columns
       r1.u = odd_lane ? make_uint2(ri0.q.z, ri0.q.w) : make_uint2(gx, gyv);      // row 2p + 1
-      if (a.out_dtype == 0 && !(a.ablate & 32)) {
+      if (a.out_dtype == 0 && !DSX_ABL(a, 32)) {
         unsigned pe[2], po[2];
         emit_row(2 * p, r0, even, &pe);
         emit_row(2 * p + 1, r1, odd, &po);

@@ -19,7 +19,10 @@ Two transports:
 
 import hashlib
 import os
+import stat
+import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -32,7 +35,11 @@ class FileRendezvous:
 
     The directory is keyed by the launcher's pid (``os.getppid()``: all ranks of a ``torchrun``
     launch share it, consecutive launches do not), its start time and ``MASTER_PORT``; ``DSX_RDZV_DIR`` overrides it
-    for launchers whose ranks do not share a parent.
+    for launchers whose ranks do not share a parent.  The directory is private (mode 0700) and must belong to the
+    calling user: a directory somebody else pre-created under the predictable name is refused, not used.
+
+    ``prefix`` namespaces the keys of one :class:`RankGroup` (its generation number inside the launch): a rank that has
+    already opened the next group never sees -- or loses -- keys of the one rank 0 is still tearing down.
     """
 
     def __init__(self, rank, world, directory=None, timeout=120.0):
@@ -48,10 +55,16 @@ class FileRendezvous:
                 pass
             directory = os.path.join(tempfile.gettempdir(), "dsx_rdzv_" + tag)
         self.dir = directory
-        os.makedirs(self.dir, exist_ok=True)
+        self.prefix = ""
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
+        st = os.stat(self.dir)
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise RuntimeError(
+                "rendezvous directory {} is not a private directory of this user (owner uid {}, mode {:o}); "
+                "set DSX_RDZV_DIR to a directory of your own".format(self.dir, st.st_uid, st.st_mode & 0o777))
 
     def _path(self, key):
-        return os.path.join(self.dir, key)
+        return os.path.join(self.dir, self.prefix + key)
 
     def put(self, key, data):
         fd, tmp = tempfile.mkstemp(dir=self.dir, prefix=".tmp_")
@@ -77,12 +90,15 @@ class FileRendezvous:
             self.get("{}.{}".format(name, r))
 
     def cleanup(self):
-        """Rank 0, after a final barrier: remove the directory."""
+        """Rank 0, after a final barrier: remove this group's keys, and the directory once it is empty (a later group
+        of the same launch may already have keys in it)."""
         if self.rank != 0:
             return
         for f in os.listdir(self.dir):
+            if self.prefix and not f.startswith(self.prefix):
+                continue
             try:
-                os.remove(self._path(f))
+                os.remove(os.path.join(self.dir, f))
             except OSError:
                 pass
         try:
@@ -96,7 +112,15 @@ class RankGroup:
 
     ``RankGroup.from_env(engine)`` reads ``RANK`` / ``WORLD_SIZE`` (set by ``torchrun``); world size 1
     needs no communicator and every collective is the identity.
+
+    Failure model of the set-up.  Stage 1 (can this rank load RCCL at all) and the outcome of stage 2 are agreed over
+    the rendezvous, so a rank that fails BEFORE the collective init takes everybody to the host transport.  Stage 2
+    itself -- ``ncclCommInitRank`` -- is a collective without a time-out: if one rank fails inside it (or dies), its
+    peers would block for good.  A watchdog thread therefore ends the process with exit code 14 and a message when
+    the init has not returned after ``DSX_COMM_TIMEOUT`` seconds (default 300): unrecoverable, but never a silent hang.
     """
+
+    _generation = 0  # groups this process has opened: every rank of a launch opens its groups in the same order
 
     def __init__(self, engine, rank, world, rendezvous=None):
         self.engine, self.rank, self.world = engine, int(rank), int(world)
@@ -113,6 +137,8 @@ class RankGroup:
         self._seq = 0
         if self.active:
             self.rdzv = rendezvous or FileRendezvous(self.rank, self.world)
+            RankGroup._generation += 1
+            self.rdzv.prefix = "g{}.".format(RankGroup._generation)
             # stage 1, no collective: can every rank load RCCL at all?  (ncclGetUniqueId on every rank; rank 0's is
             # the one that is used.)  A rank that cannot would leave the others blocked inside ncclCommInitRank.
             uid, status = b"", b"ok"
@@ -128,7 +154,8 @@ class RankGroup:
                         self.rdzv.put("rccl_unique_id", uid)
                     else:
                         uid = self.rdzv.get("rccl_unique_id")
-                    engine.comm_init(uid, self.rank, self.world)  # returns once every rank has joined
+                    with _Watchdog(float(os.environ.get("DSX_COMM_TIMEOUT", "300")), self.rank):
+                        engine.comm_init(uid, self.rank, self.world)  # returns once every rank has joined
                 except Exception as e:  # noqa: BLE001
                     status = ("failed: {}: {}".format(type(e).__name__, e)).encode()
                 bad = self._agree("comm_status", status)
@@ -242,6 +269,33 @@ class RankGroup:
                     self.engine.comm_destroy()
                 if self.rdzv is not None:
                     self.rdzv.cleanup()
+
+
+class _Watchdog:
+    """Ends the process (exit code 14) if the guarded block has not finished after ``seconds``: the collective
+    communicator init has no time-out of its own, and a peer that failed inside it never arrives."""
+
+    def __init__(self, seconds, rank):
+        self.seconds, self.rank = seconds, rank
+        self.timer = None
+
+    def _fire(self):
+        sys.stderr.write("[dsx] rank {}: the RCCL communicator init did not return within {:.0f} s (a peer failed "
+                         "inside it or died); giving up\n".format(self.rank, self.seconds))
+        sys.stderr.flush()
+        os._exit(14)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
 
 
 def z_shard(n_slices, world_size, rank, z_chunk=64):

@@ -64,6 +64,7 @@ class MiniZarrArray:
         self.fill_value = meta.get("fill_value", 0) or 0
         self.sep = meta.get("dimension_separator", ".")
         comp = meta.get("compressor")
+        self.compressor_meta = None if comp is None else dict(comp)  # as written in .zarray (matches())
         if comp is None:
             self.compressor = None
         elif comp.get("id") == "zlib":
@@ -111,21 +112,26 @@ class MiniZarrArray:
         return blosc_encode(raw, typesize, clevel, shuffle)
 
     # -- construction -------------------------------------------------------------------------
+    @staticmethod
+    def _compressor_meta(compressor):
+        """The ``compressor`` entry of ``.zarray`` for what :meth:`create` accepts."""
+        if compressor is None:
+            return None
+        if compressor == "zlib":
+            return {"id": "zlib", "level": 1}
+        if compressor == "blosc":
+            return dict(BLOSC_ZSTD)
+        if isinstance(compressor, dict):
+            return dict(compressor)  # a numcodecs get_config() dict
+        raise NotImplementedError("compressors: None, 'zlib', 'blosc' or a numcodecs config dict")
+
     @classmethod
     def create(cls, path, shape, chunks, dtype, compressor=None, dimension_separator="/", fill_value=0,
                overwrite=True):  # fmt: skip
         os.makedirs(path, exist_ok=True)
         if not overwrite and os.path.exists(os.path.join(path, ".zarray")):
             raise FileExistsError(path)
-        comp = None
-        if compressor == "zlib":
-            comp = {"id": "zlib", "level": 1}
-        elif compressor == "blosc":
-            comp = dict(BLOSC_ZSTD)
-        elif isinstance(compressor, dict):
-            comp = dict(compressor)  # a numcodecs get_config() dict
-        elif compressor is not None:
-            raise NotImplementedError("compressors: None, 'zlib', 'blosc' or a numcodecs config dict")
+        comp = cls._compressor_meta(compressor)
         meta = {
             "zarr_format": 2,
             "shape": list(shape),
@@ -150,10 +156,15 @@ class MiniZarrArray:
         with open(os.path.join(path, ".zarray")) as f:
             return cls(path, json.load(f))
 
-    def matches(self, shape, chunks, dtype):
-        """Does this array have the given geometry (used to tell a freshly created array from a stale one)?"""
-        return (self.shape == tuple(int(x) for x in shape) and self.chunks == tuple(int(x) for x in chunks)
-                and self.dtype == np.dtype(dtype))
+    def matches(self, shape, chunks, dtype, compressor=Ellipsis):
+        """Does this array have the given geometry -- and, when ``compressor`` is given (what :meth:`create` takes),
+        the given codec?  Tells the array rank 0 has just created from a stale one: a left-over of an earlier run with
+        ANOTHER codec has the same geometry, and a rank that opened it would write chunks the new metadata cannot read."""
+        ok = (self.shape == tuple(int(x) for x in shape) and self.chunks == tuple(int(x) for x in chunks)
+              and self.dtype == np.dtype(dtype))
+        if ok and compressor is not Ellipsis:
+            ok = self.compressor_meta == self._compressor_meta(compressor)
+        return ok
 
     # -- chunk io -----------------------------------------------------------------------------
     def _chunk_path(self, idx):

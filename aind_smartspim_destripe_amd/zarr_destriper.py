@@ -447,9 +447,10 @@ def destripe_zarr(
     the metadata file appears atomically.  ``group`` (anything with ``barrier()``: a
     ``distributed.RankGroup`` / ``FileRendezvous``-based barrier, or a ``torch.distributed`` wrapper)
     orders that creation before the other ranks open the array; without a group they poll until the
-    metadata on disk has the geometry of THIS run (a stale array of another shape is never used; one of the
-    same shape is indistinguishable and harmless: rank 0 rewrites the same metadata, every rank rewrites
-    its own chunks).  ``device=None`` takes the local rank (``LOCAL_RANK``), not the global one.
+    metadata on disk has the geometry AND the codec of THIS run (a stale array of another shape or another
+    compressor is never used -- chunks written under stale metadata would not be readable under the new one; a
+    left-over with the same geometry and codec is indistinguishable and harmless: rank 0 rewrites the same
+    metadata, every rank rewrites its own chunks).  ``device=None`` takes the local rank (``LOCAL_RANK``), not the global one.
 
     ``device_retile``: ``True`` = chunks are re-tiled into planes and back on the GPU (row f1; needs a
     uint16 store and chunk-aligned z blocks), ``False`` = host gather / scatter through
@@ -471,7 +472,7 @@ def destripe_zarr(
     for _ in range(1200):  # without a group: wait for rank 0's metadata of this geometry
         try:
             dst = MiniZarrArray.open(output_path)
-            if dst.matches(out_shape, out_chunks, np.uint16):
+            if dst.matches(out_shape, out_chunks, np.uint16, compressor):
                 break
         except (FileNotFoundError, ValueError):
             pass

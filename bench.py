@@ -5,8 +5,11 @@
 
 One "step" = one pass of the hot path (filter_stripes semantics, production parameters,
 uint16 in -> uint16 out) over a batch of 256 synthetic striped slices that is already resident in
-HBM.  N > 1: launched by torch.distributed.run (the launcher only: RANK / LOCAL_RANK / WORLD_SIZE), one
-rank per GPU; slices shard embarrassingly (weak scaling, 256 slices per rank).  The only collective
+HBM.  N > 1: one rank per GPU, either launched by torch.distributed.run (the launcher only: RANK /
+LOCAL_RANK / WORLD_SIZE) or -- when `python bench.py --gpus N` is run by itself, without WORLD_SIZE in
+the environment -- started by this script: the parent touches no GPU, starts N child processes of itself
+with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* / DSX_RDZV_DIR set, relays rank 0's JSON line and exits
+non-zero if any rank does.  Slices shard embarrassingly (weak scaling, 256 slices per rank).  The only collective
 is one RCCL broadcast of the filter-constant blob before the timed region; it, the barriers and the
 max-over-ranks of the time go straight through the C ABI (dsx_comm_*, librccl.so; no torch).
 A failing collective or a result that does not verify ends the run with a non-zero exit code.
@@ -175,9 +178,75 @@ def verify(engine, stack, d_out, h, w, batch, cohort, n_streams, shading, wavele
     return ok, details
 
 
+def requested_gpus(argv):
+    """--gpus N of the command line (without building the whole parser: the launcher path runs before anything else)."""
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh processes; this parent never
+    loads the library or touches a GPU), relay rank 0's stdout (the JSON line), and return the worst exit code.  A rank
+    that fails takes the others down after a grace period (they may be waiting for it in a rendezvous)."""
+    import socket
+    import subprocess
+    import tempfile
+
+    with socket.socket() as sk:  # a free port for MASTER_PORT (rendezvous tag; nothing listens on it)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    rdzv = tempfile.mkdtemp(prefix="dsx_rdzv_bench_")  # private (0700), ours
+    kids = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DSX_RDZV_DIR=rdzv,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))  # fmt: skip
+        kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                     stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))  # fmt: skip
+    log("[bench] launcher: started {} ranks (pids {}), rendezvous {}".format(n, [k.pid for k in kids], rdzv))
+    codes = [None] * n
+    first_failure = None
+    out0 = b""
+    try:
+        while any(c is None for c in codes):
+            for i, k in enumerate(kids):
+                if codes[i] is None and k.poll() is not None:
+                    codes[i] = k.returncode
+                    if i == 0:
+                        out0 = k.stdout.read()
+                    if k.returncode != 0 and first_failure is None:
+                        first_failure = time.time()
+                        log("[bench] launcher: rank {} exited with code {}".format(i, k.returncode))
+            if first_failure is not None and time.time() - first_failure > 20.0:
+                for i, k in enumerate(kids):  # exactly the processes started above
+                    if codes[i] is None:
+                        k.kill()
+            time.sleep(0.05)
+    finally:
+        for i, k in enumerate(kids):
+            if k.poll() is None:
+                k.kill()
+        try:
+            for f in os.listdir(rdzv):
+                os.remove(os.path.join(rdzv, f))
+            os.rmdir(rdzv)
+        except OSError:
+            pass
+    sys.stdout.buffer.write(out0)
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    return 0 if not bad else (bad[0] if bad[0] and bad[0] > 0 else 1)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
+    if "WORLD_SIZE" not in os.environ and requested_gpus(sys.argv[1:]) > 1:
+        sys.exit(launch_ranks(requested_gpus(sys.argv[1:]), sys.argv[1:]))
     # Only the JSON line may reach stdout: library banners (RCCL) are written to fd 1 directly,
     # so fd 1 is pointed at stderr for the duration of the run and the line goes to the saved fd.
     sys.stdout.flush()
@@ -303,15 +372,26 @@ def main():
         # HBM bytes per launch chain from the PMC counters: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of
         # tools/traffic.sh on this bench, corrected as MI355X_MICROARCH.md prescribes.  The figure is a
         # property of a BUILD: it is reported only when the profile names this configuration, with its source.
+        # The profile carries the sha256 of the native sources it was measured on (build_hash, __graft_entry__.
+        # source_hash); the loaded library carries the same stamp (libdsx_hip.so.srchash): no match, no figure.
         traffic, traffic_source = None, None
+        try:
+            with open(eng_mod.LIB_PATH + ".srchash") as f:
+                lib_hash = f.read().strip()
+        except OSError:
+            lib_hash = None
         for name in sorted(os.listdir(os.path.join(REPO, "profiles")), reverse=True):
             if name.endswith("_traffic.json"):
                 with open(os.path.join(REPO, "profiles", name)) as f:
                     t = json.load(f)
                 if t.get("planes_per_step") == args.batch and t.get("shape", "2048x2048") == "{}x{}".format(H, W) \
                         and bool(t.get("shading", False)) == bool(args.shading) and args.wavelet == "db3":
-                    traffic = int(t["hbm_bytes_per_step"])
-                    traffic_source = "profiles/{} ({})".format(name, t.get("build", "build not recorded"))
+                    if lib_hash is not None and t.get("build_hash") == lib_hash:
+                        traffic = int(t["hbm_bytes_per_step"])
+                        traffic_source = "profiles/{} (build_hash {} = the loaded library)".format(name, lib_hash[:12])
+                    else:
+                        traffic_source = "profiles/{} was measured on another build (hash {}, library {}): not reported".format(
+                            name, str(t.get("build_hash"))[:12], str(lib_hash)[:12])
                     break
         result = {
             "metric": "{}x{} uint16 slices/s destriped".format(H, W),

@@ -220,3 +220,32 @@ def check_plane(out, img, deltas, what, cfg, max_flips, ref=None, stages=None, p
         what, flips, n_bad, float(rel.max()), "" if forced is None else "; strict with the flips forced",
         "" if not tie_levels else "; Otsu tie at level index {} (engine's bin taken in the oracle)".format(tie_levels)))
     return n_bad, flips
+
+
+# ---- chunk-map results (uint16 stores, optional shading) against the oracle ------------------------------------------
+def stream_part_picks(block_z, z0, z1, n_streams=4):
+    """One plane of every sub-cohort stream part of the z-block [z0, z1) as the engine splits it (dsx.hip
+    run_cohort_split: parts of ceil(nb / parts) planes, a part never smaller than 16 planes)."""
+    nb = z1 - z0
+    parts = n_streams
+    while parts > 1 and nb // parts < 16:
+        parts -= 1
+    per = (nb + parts - 1) // parts
+    return sorted({z0 + min(nb - 1, i * per + (5 * i + 3) % max(per, 1)) for i in range(parts)})
+
+
+def u16_plane_against_oracle(got, plane, tile_name, shadow_correction, what):
+    """A stored uint16 plane against ``orc.filter_stripes`` (+ flatfield_correction when shading is on) of the input
+    plane.  The cast truncates, so a float32 result within 1e-4 of an integer may land one count away; a mask decision
+    that fell the other way at a near-threshold coefficient (module docstring) moves the pixels of its row band by
+    more: those are bounded in number (one flip reaches <= 0.1 % of a plane) and in size."""
+    ref = orc.filter_stripes(plane, tile_name, synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, shadow_correction,
+                             synth.ZARR_PATH_HIGH_INT)  # fmt: skip
+    ref = np.clip(ref, 0, 65535).astype(np.uint16).astype(np.int64)
+    d = np.abs(got.astype(np.int64) - ref)
+    far = d > np.maximum(1, 2e-4 * ref)
+    stats = {"off_by_one": float((d > 0).mean()), "beyond": float(far.mean()), "worst": int(d.max())}
+    assert far.mean() <= 2e-3, (what, stats)
+    assert (d > 0).mean() < 1e-2, (what, stats)
+    assert d.max() <= max(2, 0.05 * ref.max()), (what, stats)
+    return stats

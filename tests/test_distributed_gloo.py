@@ -298,6 +298,74 @@ def test_file_rendezvous_atomic_and_timeout(tmp_path):
     assert not os.path.exists(str(tmp_path)) or not os.listdir(str(tmp_path))
 
 
+def test_file_rendezvous_refuses_a_directory_it_does_not_own_privately(tmp_path):
+    """The default directory name is predictable and lives in the world-writable temp dir: a directory somebody
+    else could write to (here: group / other bits set) must be refused, not trusted."""
+    from aind_smartspim_destripe_amd.distributed import FileRendezvous
+
+    d = tmp_path / "loose"
+    d.mkdir()
+    os.chmod(str(d), 0o777)
+    with pytest.raises(RuntimeError, match="not a private directory"):
+        FileRendezvous(0, 2, str(d))
+    os.chmod(str(d), 0o700)
+    FileRendezvous(0, 2, str(d))  # fine once private
+    fresh = tmp_path / "made_by_us"
+    FileRendezvous(0, 2, str(fresh))
+    assert (os.stat(str(fresh)).st_mode & 0o777) == 0o700
+
+
+def _two_groups_worker(rank, world, xdir, q):
+    sys.path.insert(0, REPO)
+    import time
+
+    from aind_smartspim_destripe_amd import distributed as dd
+
+    out = []
+    for gen in range(2):
+        eng = _FakeEngine(rank, world, xdir)
+        eng.comm_init = lambda *a: (_ for _ in ()).throw(OSError("no RCCL here"))  # -> host transport: all in files
+        grp = dd.RankGroup(eng, rank, world, dd.FileRendezvous(rank, world, xdir, timeout=20.0))
+        out.append(grp.allreduce([float(rank + 10 * gen)], "sum")[0])
+        if rank == 0 and gen == 0:
+            time.sleep(0.5)  # rank 0 is slow to tear group 1 down: rank 1 is already inside group 2 by then
+        grp.close()
+    q.put((rank, out))
+
+
+def test_consecutive_rank_groups_of_one_launch_do_not_touch_each_others_keys(tmp_path):
+    """Keys are namespaced per group generation: a fast rank that has opened the next RankGroup keeps its fresh keys
+    while rank 0 is still removing the previous group's (they used to share names: a deleted 'preflight' key meant a
+    120 s time-out, a stale unique id a wrong communicator)."""
+    import multiprocessing as mp
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_groups_worker, args=(r, world, str(tmp_path / "rdzv"), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, [1.0, 21.0]), (1, [1.0, 21.0])], res
+
+
+def test_comm_init_watchdog_ends_a_rank_whose_peer_never_arrives(tmp_path):
+    """ncclCommInitRank has no time-out: the watchdog turns 'blocked for good' into exit code 14 and a message."""
+    import subprocess
+
+    code = (
+        "import sys, time; sys.path.insert(0, {!r})\n"
+        "from aind_smartspim_destripe_amd.distributed import _Watchdog\n"
+        "with _Watchdog(0.3, 5):\n"
+        "    time.sleep(30)\n"
+    ).format(REPO)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 14 and "rank 5" in r.stderr and "did not return" in r.stderr
+
+
 # ---- destripe_zarr under two ranks on ONE store (engine replaced by the CPU oracle) ---------------------
 class _RdzvBarrier:
     def __init__(self, rank, world, directory):
@@ -365,6 +433,55 @@ def test_two_rank_destripe_zarr_matches_single_rank(tmp_path):
     assert a.shape == b.shape == (1, 1, 12, 48, 64)
     np.testing.assert_array_equal(a[0, 0], b[0, 0])
     assert a[0, 0].std() > 0
+
+
+def _zarr_rank_worker_nogroup(rank, world, src_path, out_path, delay, q):
+    sys.path.insert(0, REPO)
+    import time
+
+    from aind_smartspim_destripe_amd import filtering as fl
+    from aind_smartspim_destripe_amd import synth, zarr_destriper as zd
+
+    fl.destripe_planes = _oracle_destripe_planes
+    time.sleep(delay)
+    n, _ = zd.destripe_zarr(src_path, out_path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, None,
+                            prediction_chunksize=(4, 48, 64), output_chunks=(1, 1, 4, 16, 16), rank=rank,
+                            world_size=world, device=0, device_retile=False, group=None, compressor="blosc")  # fmt: skip
+    q.put((rank, n))
+
+
+def test_groupless_rank_ignores_a_stale_array_of_the_same_geometry_but_another_codec(tmp_path):
+    """No barrier between the ranks: rank 1 polls the metadata.  The output directory holds the array of an earlier
+    RAW run with the very same geometry; rank 1 starts first and must wait for rank 0's Blosc metadata instead of
+    writing raw chunks under it (the store would be unreadable, with no error anywhere)."""
+    import multiprocessing as mp
+
+    from aind_smartspim_destripe_amd import synth
+    from aind_smartspim_destripe_amd.mini_zarr import MiniZarrArray
+
+    vol = np.stack([synth.synthetic_plane(k, 48, 64) for k in range(8)])
+    src = MiniZarrArray.create(str(tmp_path / "in.zarr"), (1, 1, 8, 48, 64), (1, 1, 4, 16, 16), np.uint16)
+    src[0, 0] = vol
+    stale = MiniZarrArray.create(str(tmp_path / "out.zarr"), (1, 1, 8, 48, 64), (1, 1, 4, 16, 16), np.uint16, compressor=None)
+    assert stale.matches((1, 1, 8, 48, 64), (1, 1, 4, 16, 16), np.uint16)
+    assert not stale.matches((1, 1, 8, 48, 64), (1, 1, 4, 16, 16), np.uint16, "blosc")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_zarr_rank_worker_nogroup,
+                         args=(r, 2, str(tmp_path / "in.zarr"), str(tmp_path / "out.zarr"), 1.5 if r == 0 else 0.0, q))
+             for r in range(2)]  # fmt: skip
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, 4), (1, 4)]
+    out = MiniZarrArray.open(str(tmp_path / "out.zarr"))
+    assert out.compressor is not None and out.compressor[0] == "blosc"
+    res = out[0, 0]  # every chunk decodes as a Blosc frame: nobody wrote raw bytes under the new metadata
+    ref = _oracle_destripe_planes(vol, "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, 2500)
+    np.testing.assert_array_equal(res, ref)
 
 
 def test_destripe_channel_needs_group_for_many_ranks(tmp_path):

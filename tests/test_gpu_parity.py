@@ -390,6 +390,8 @@ def _engine_with_streams(n):
         (128, (512, 512), 16),   # 4 parts of 32 planes, 6 levels
         (68, (640, 640), 17),    # 4 parts of 17 planes, 7 levels: control-block slices that are not
                                  # 16-byte aligned (k_zero3's fallback branch), ragged last part
+        (64, (1800, 1800), 6),   # BASELINE configs[4]: non-power-of-two tile, embedded mixed-radix plans (1815, 960)
+        (64, (1600, 2000), 6),   # the production tile (zarr_destriper.py:1256 of the reference), plans 2048 / 1024
     ],
 )
 def test_multistream_cohort(n, shape, n_unique, golden_large):
@@ -665,48 +667,90 @@ def test_graph_replay_is_bit_identical_to_eager_launches(monkeypatch):
         e.close()
 
 
-def test_fused_histogram_row_filter_is_bit_identical_to_the_separate_kernels(monkeypatch):
-    """Levels 1 / 2 of 2048-wide planes make their histogram, Otsu value and threshold inside the row-filter kernel
-    (k_rowfilter<..., HIST>: ticketed work items, plane barrier in global memory).  Integer counts and the same Otsu
-    code: results, Otsu values and thresholds must be bit-identical to the chain with k_hist / k_otsu (DSX_FUSE_HIST=0),
-    for an unsplit cohort (helper stream), a cohort split over the four streams, and a plane of constant rows (constant
-    cH^2: no histogram at all).
-
-    The switch is an experiment (off by default).  Before the launch carried spare workgroups the
-    barrier of the last plane of a launch ran into the kernel's bound about one launch in four (reported through
-    PlaneStats::flags -> DsxError, never a hang); a run that reports it is still repeated here, and the count printed."""
+def test_timing_switches_do_nothing_in_the_product_build(monkeypatch):
+    """The timing-only switches of the measurement builds (DSX_ABLATE, DSX_SKIP_HIST / _ROW / _COARSE: kernels skip a phase
+    or a launch and return WRONG pixels) are compiled in under -DDSX_DIAG only (tools/build_variant.sh).  The library the
+    package ships must return the same bits whatever those variables say; the fused histogram / row-filter experiment of
+    round 2 (DSX_FUSE_HIST, an inter-block spin barrier) is gone from the sources altogether."""
     h, w = 2048, 2048
-    bank = synth.synthetic_bank(6, h, w)
-    flatp = np.full((h, w), 300, np.uint16)  # cH == 0 everywhere: min == max at every level
-    rows = np.repeat((100 + 50 * np.arange(h, dtype=np.uint16) % 7)[:, None], w, axis=1).astype(np.uint16)
-    stack = np.concatenate([bank, flatp[None], rows[None], synth.synthetic_stack(64, h, w, bank=bank)])  # 72 planes
+    bank = synth.synthetic_bank(4, h, w)
+    stack = synth.synthetic_stack(72, h, w, bank=bank)  # 72 planes: 4 parts of 18 on the four streams
     res = {}
-    timeouts = 0
-    for mode in ("0", "1", "3"):
-        monkeypatch.setenv("DSX_FUSE_HIST", mode)
-        for attempt in range(6):
-            e = eng_mod.DestripeEngine(0)
-            try:
-                e.plan(h, w, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT, max_batch=72)
-                small = e.run(stack[:8], out_dtype=np.float32)            # one part, helper stream
-                thr_small = [[e.thresholds(k, lv) for lv in range(e.levels)] for k in range(8)]
-                big, cfg = e.run(stack, out_dtype=np.uint16, return_cfg=True)  # 72 planes: 4 parts of 18
-                thr_big = [[e.thresholds(k, lv) for lv in range(e.levels)] for k in (0, 6, 7, 17, 18, 40, 71)]
-                res[mode] = (small, thr_small, big, cfg, thr_big)
-                break
-            except eng_mod.DsxError as err:
-                if "plane barrier" not in str(err) or mode == "0":
-                    raise
-                timeouts += 1
-                print("[fused-hist] DSX_FUSE_HIST={} attempt {}: {}".format(mode, attempt, str(err)[-120:]))
-            finally:
-                e.close()
-    print("[fused-hist] barrier time-outs reported and repeated: {}".format(timeouts))
-    assert "0" in res and len(res) >= 2, "no fused run completed"
-    for mode in [m for m in ("1", "3") if m in res]:
-        for a, b in zip(res[mode], res["0"]):
-            np.testing.assert_array_equal(np.asarray(a), np.asarray(b), err_msg="DSX_FUSE_HIST=" + mode)
+    for mode in ("plain", "switched"):
+        if mode == "switched":
+            for k, v in (("DSX_ABLATE", str(1 | 2 | 4 | 16 | 32)), ("DSX_SKIP_HIST", "1"), ("DSX_SKIP_ROW", "3"),
+                         ("DSX_SKIP_COARSE", "2"), ("DSX_FUSE_HIST", "3")):
+                monkeypatch.setenv(k, v)
+        e = eng_mod.DestripeEngine(0)
+        try:
+            e.plan(h, w, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT, max_batch=72)
+            small = e.run(stack[:8], out_dtype=np.float32)            # one part, helper stream
+            thr_small = [[e.thresholds(k, lv) for lv in range(e.levels)] for k in range(8)]
+            big, cfg = e.run(stack, out_dtype=np.uint16, return_cfg=True)
+            res[mode] = (small, thr_small, big, cfg)
+        finally:
+            e.close()
+    for a, b in zip(res["switched"], res["plain"]):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
     # and the reference: plane 1 of the stack against the oracle
     ref = orc.filter_stripes(stack[1], "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT)
-    d = np.abs(res["0"][2][1].astype(np.int64) - ref.astype(np.uint16).astype(np.int64))
+    d = np.abs(res["switched"][2][1].astype(np.int64) - ref.astype(np.uint16).astype(np.int64))
     assert d.max() <= 1
+
+
+def test_device_buffer_path_reports_non_finite_planes_at_the_next_sync():
+    """float32 planes with a pixel whose log(1 + x) is not finite: the reference dies in numpy.histogram (ValueError).
+    dsx_run_host raises at the call; the asynchronous dsx_run_device cannot, so the flag is folded into a sticky word of
+    the context and the NEXT synchronising entry point raises the same ValueError, once."""
+    h, w = 96, 128
+    planes = synth.synthetic_bank(3, h, w).astype(np.float32)
+    bad = planes.copy()
+    bad[1, 40, 50] = np.nan
+    e = eng_mod.DestripeEngine(0)
+    try:
+        e.plan(h, w, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT, max_batch=4)
+        d_in, d_out = e.alloc(bad.nbytes), e.alloc(bad.nbytes)
+        try:
+            d_in.upload(bad)
+            e.run_device(d_in, np.float32, 3, d_out, np.float32)
+            with pytest.raises(ValueError, match="not finite"):
+                e.sync()
+            e.sync()  # reported once
+            d_in.upload(planes)
+            e.run_device(d_in, np.float32, 3, d_out, np.float32)
+            e.sync()
+            good = d_out.download((3, h, w), np.float32)
+        finally:
+            d_in.free()
+            d_out.free()
+        np.testing.assert_array_equal(good, e.run(planes, out_dtype=np.float32))
+        with pytest.raises(ValueError, match="not finite"):  # the host-buffer call raises by itself ...
+            e.run(bad, out_dtype=np.float32)
+        e.sync()                                              # ... and leaves nothing behind
+    finally:
+        e.close()
+
+
+def test_bench_self_launch_two_ranks_on_the_one_gpu():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE -- the driver's command -- must start two ranks by
+    itself.  Rehearsed on the one GPU of this box (DSX_SHARE_GPU=1: both ranks on device 0; RCCL refuses two ranks on
+    one device, so the ranks agree on the host transport): the line must say n_gpus 2, carry both ranks' slices, and
+    verify."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSX_RDZV_DIR")}
+    env["DSX_SHARE_GPU"] = "1"
+    r = subprocess.run(
+        [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32",
+         "--settle", "0", "--shape", "512x512"],
+        capture_output=True, text=True, timeout=600, env=env)  # fmt: skip
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["scaling"] == "weak"
+    assert d["config"]["ranks_share_gpus"] is True and d["config"]["rank_transport"] in ("host", "rccl")
+    assert abs(d["value"] - 2 * 32 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-2 * d["value"]

@@ -100,3 +100,19 @@ def test_row_filter_spectral_pipeline(host_check, args):
     length-w circular operator with the fftpack packed-index gains."""
     r = host_check("rows", *args)
     assert r["rel_err"] < 3e-6, r
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself_and_fails_loudly_without_gpus(lib):
+    """`python bench.py --gpus 2` as the driver runs it (no torchrun, no WORLD_SIZE): the parent must start two ranks
+    itself.  On this GPU-less machine every rank dies in dsx_init; the launcher must report it and exit non-zero
+    without printing a result line."""
+    if lib.dsx_device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the -m gpu rehearsal")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(
+        [os.sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+         "--cpu-planes", "0", "--settle", "0", "--shape", "64x64"],
+        capture_output=True, text=True, timeout=300, env=env)  # fmt: skip
+    assert r.returncode != 0
+    assert "started 2 ranks" in r.stderr and "no HIP device" in r.stderr
+    assert r.stdout.strip() == ""

@@ -115,3 +115,63 @@ def test_destripe_zarr_end_to_end(tmp_path):
         ref = orc.filter_stripes(stack[z], "X_0_Y_0", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, 2500)
         d = np.abs(out[z].astype(np.int64) - np.clip(ref, 0, 65535).astype(np.uint16).astype(np.int64))
         assert d.max() <= 1 and (d > 0).mean() < 2e-3, (z, int(d.max()))
+
+
+@pytest.mark.gpu
+def test_chunk_map_at_production_geometry_against_the_oracle(tmp_path):
+    """BASELINE configs[3] at the geometry production runs it in (zarr_destriper.py:253-336, 1252-1267 of the reference):
+    the 1600 x 2000 tile, 64-plane blocks (``prediction_chunksize=(64, H, W)``), chunks ``(1, 1, 64, 128, 128)``,
+    Blosc-zstd in and out, dark / flat-field correction on.  192 planes = 3 blocks: both staging buffer sets wrap, every
+    block is split into 4 stream parts INSIDE the 3-stream upload / compute / download pipeline, with the deferred joins
+    between ``run_device`` and ``planes_to_bricks``.
+
+    * one plane of EVERY stream part of EVERY block against the oracle (filter_stripes + flatfield_correction),
+    * planes 0 and 1 against the samples the real reference wrote (tests/golden/large_stats.npz; pushed through
+      flatfield_correction's arithmetic),
+    * the whole store byte-identical to the host gather / scatter path (execute_worker -> destripe_planes)."""
+    from parity_util import stream_part_picks, u16_plane_against_oracle
+
+    H, W, Z, BZ = 1600, 2000, 192, 64
+    bank = synth.synthetic_bank(8, H, W)
+    vol = synth.synthetic_stack(Z, H, W, bank=bank)
+    yy, xx = np.mgrid[0:H, 0:W]
+    r2 = ((yy - H / 2.0) / (H / 2.0)) ** 2 + ((xx - W / 2.0) / (W / 2.0)) ** 2
+    flat = (1.0 - 0.15 * r2).astype(np.float32)
+    dark = np.full((H, W), 100.0, dtype=np.float32)
+    sc = {"retrospective": True, "flatfield": flat, "darkfield": dark}
+    name = "X_0_Y_0.zarr"
+    src = MiniZarrArray.create(str(tmp_path / name), (1, 1, Z, H, W), (1, 1, 64, 128, 128), np.uint16, compressor="blosc")
+    for z in range(0, Z, BZ):
+        src[0, 0, z : z + BZ] = vol[z : z + BZ]
+    outs = {}
+    for mode in (True, False):
+        path = str(tmp_path / "out_{}.zarr".format(int(mode)))
+        n, _ = zd.destripe_zarr(str(tmp_path / name), path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, sc,
+                                prediction_chunksize=(BZ, H, W), output_chunks=(1, 1, 64, 128, 128), device=0,
+                                device_retile=mode, compressor="blosc", io_threads=16)  # fmt: skip
+        assert n == Z
+        outs[mode] = MiniZarrArray.open(path)
+        assert outs[mode].compressor[0] == "blosc"
+    zd.release_staging()
+    dev = outs[True][0, 0]
+    assert dev.shape == (Z, H, W) and dev.dtype == np.uint16
+    # (1) every stream part of every block
+    picks = [z for b in range(0, Z, BZ) for z in stream_part_picks(BZ, b, b + BZ)]
+    assert len(picks) == 12
+    for z in picks:
+        st = u16_plane_against_oracle(dev[z], vol[z], name.replace(".zarr", ""), sc, ("chunk map", z))
+        print("[chunk map] plane {:3d}: off by one count {:.2e}, beyond {:.2e}, worst {}".format(
+            z, st["off_by_one"], st["beyond"], st["worst"]))
+    # (2) the real reference's samples of bank planes 0, 1 (= stack planes 0, 1)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_stats.npz"), allow_pickle=False)
+    rs = np.random.RandomState(7)
+    sy, sx = rs.randint(0, H, 4096), rs.randint(0, W, 4096)
+    for k in (0, 1):
+        ref = g["s1600x2000__k{}__u16__sample".format(k)]
+        d_ = dark[sy, sx].astype(np.float64)
+        ref = np.where(ref > d_, ref - d_, 0.0) / flat[sy, sx].astype(np.float64)
+        want = np.clip(ref, 0, 65535).astype(np.uint16).astype(np.int64)
+        diff = np.abs(dev[k][sy, sx].astype(np.int64) - want)
+        assert int((diff > np.maximum(1, 2e-4 * want)).sum()) <= 4, (k, int(diff.max()))  # k1 has one known flip
+    # (3) device brick path == host gather / scatter path, byte for byte
+    np.testing.assert_array_equal(dev, outs[False][0, 0])

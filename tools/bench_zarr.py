@@ -32,9 +32,40 @@ try:
     out = MiniZarrArray.open(os.path.join(root, "out.zarr"))
     chk = int(out[0, 0, 0].astype(np.uint64).sum())
     v = res["overlapped"]["planes"] / res["overlapped"]["seconds"]
+    # ---- verification (tests/test_zarr_chunk_map.py::test_chunk_map_at_production_geometry_against_the_oracle holds the
+    # same statement on a 192-plane store): one plane of every stream part of the first, a middle and the last block --
+    # bit-identical to the same plane filtered alone (one launch chain, one stream); the first block's picks and planes
+    # 0 / 1 also against the CPU oracle (uint16 truncation: one count; see parity_util.u16_plane_against_oracle)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from parity_util import stream_part_picks, u16_plane_against_oracle
+    from aind_smartspim_destripe_amd import filtering as fl
+    nblk = (n + 63) // 64
+    blocks = sorted({0, nblk // 2, nblk - 1})
+    verified, checked, oracle_checked = True, [], []
+    for b in blocks:
+        z0, z1 = 64 * b, min(64 * b + 64, n)
+        for z in stream_part_picks(64, z0, z1):
+            plane_in = src[0, 0, z]
+            got = out[0, 0, z]
+            alone = fl.destripe_planes(plane_in[None], "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, 2500,
+                                       out_dtype=np.uint16, max_batch=1)[0]
+            if not np.array_equal(alone, got):
+                verified = False
+            checked.append(int(z))
+            if b == 0:
+                try:
+                    u16_plane_against_oracle(got, plane_in, "t", None, ("bench_zarr", z))
+                    oracle_checked.append(int(z))
+                except AssertionError as e:
+                    verified = False
+                    print("oracle mismatch", e, file=sys.stderr)
     print(json.dumps({"metric": "2048x2048 uint16 slices/s, Zarr store to Zarr store ({} chunks, tmpfs)".format(codec or "raw"), "value": round(v, 1),
                       "planes": n, "seconds": res["overlapped"]["seconds"], "store_make_s": round(t_make, 1),
                       "roofline": {"bound": "host link", "peak_planes_per_s": 3750, "frac": round(v / 3750.0, 3)},
-                      "plane0_checksum": chk}))
+                      "plane0_checksum": chk, "verified": verified,
+                      "verification": {"planes_bit_identical_to_single_plane_runs": checked,
+                                       "planes_against_the_cpu_oracle": oracle_checked, "blocks": blocks}}))
+    if not verified:
+        sys.exit(3)
 finally:
     shutil.rmtree(root, ignore_errors=True)

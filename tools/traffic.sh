@@ -30,12 +30,14 @@ shape = "2048x2048"
 if "--shape" in extra:
     shape = extra.split("--shape")[1].split()[0]
 try:
-    build = open("gpurun_out/.build_id").read().strip()
+    build_hash = open("aind_smartspim_destripe_amd/_lib/libdsx_hip.so.srchash").read().strip()
 except Exception:
-    build = "working tree at " + __import__("time").strftime("%Y-%m-%d %H:%M")
+    build_hash = None
+build = "measured " + __import__("time").strftime("%Y-%m-%d %H:%M") + " on the library stamped " + str(build_hash)[:12]
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/traffic.sh) on python3 bench.py --steps 2 --warmup 1 --settle 0 --no-verify --cpu-planes 0 " + extra,
     "build": build,
+    "build_hash": build_hash,
     "shape": shape,
     "shading": "--shading" in extra,
     "correction": "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as is; units KB -> bytes x1000",
