@@ -872,115 +872,99 @@ struct HistArgs {
 // Bin of q = largest i with edges[i] <= q (numpy's estimate-then-correct rule ends there too).
 // The edges are numpy.linspace's of the reference's pinned NumPy 1.26.4: float32 end points are
 // promoted to float64, edges[i] = i * ((max - min) / 256) + min in float64 (separate multiply and
-// add), then rounded to float32.  The estimate (q - qmin) * scale is within 1e-4 of the exact
-// position, so only values within 1e-3 of an integer need the comparison against the actual edges.
+// add), then rounded to float32.  The estimate (q - qmin) * scale (the subtraction first: exact for q near qmin,
+// so the estimate stays within 1e-4 bins however narrow the range) is corrected against the actual edges.
 struct HistBins {
-  float qmin, qmax, scale, off;
+  float qmin, qmax, scale;
   double first64, step64;
   __device__ __forceinline__ HistBins(float lo, float hi) : qmin(lo), qmax(hi) {
     scale = 256.0f / (qmax - qmin);
-    off = -qmin * scale;
     first64 = (double)qmin;
     step64 = ((double)qmax - (double)qmin) / 256.0;
   }
   __device__ __forceinline__ float edge(int i) const { return (float)__dadd_rn(__dmul_rn((double)i, step64), first64); }
-  __device__ __forceinline__ int operator()(float q) const {
-    const float fi = fmaf(q, scale, off);  // = (q - qmin) * scale to a few ulp of 256
-    int idx = min((int)fi, 255);
-    const float fr = __builtin_amdgcn_fractf(fi);  // 0 for the clamped q == qmax: takes the exact path
-    if (fabsf(fr - 0.5f) > 0.499f) {
-      const float e_lo = edge(idx);
-      const float e_hi = (idx == 255) ? qmax : edge(idx + 1);
-      if (q < e_lo) idx -= 1;
-      else if (idx != 255 && q >= e_hi) idx += 1;
-      idx = max(idx, 0);
-    }
-    return idx;
-  }
 };
 
+// Round 3: branch-free binning.  Round 2's kernel spent 24 vector instructions and ~10 exec-mask branches per value
+// (an "is the estimate near an edge" test in front of a float64 edge evaluation, byte-packed counters for the four
+// lowest bins, LDS atomics under a branch for the rest).  Now the 257 float32 edges of the plane are built ONCE per
+// block (one per thread, the same float64 arithmetic as before) into LDS, and every value takes the same path:
+//     i0 = min(int((q - qmin) * scale), 255);  (e_lo, e_hi) = edges[i0], edges[i0 + 1];  (one ds_read2_b32; most
+//     idx = i0 - (q < e_lo) + (q >= e_hi)       lanes read the same pair: broadcast, no bank conflict)
+// which is numpy's estimate-then-correct rule with the correction always applied (the estimate is within 1e-4 bins,
+// the correction moves it by at most one), and one conflict-free LDS atomic: every lane owns a 16-bit counter per bin
+// (256 bins x 32 dwords, lane pair per dword, the four waves of the block share them -- at most 4 x the values of a
+// thread, far below 65536).  10 vector + 2 LDS instructions per value; no data-dependent branch.
+constexpr int kHistLoads = 8;  // 16-byte loads in flight per lane
+
 __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
-  __shared__ unsigned s_h[256];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) unsigned s_cnt[256 * 32];
+  __shared__ float s_edge[264];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int plane = blockIdx.y;
   const unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
   const float qmin = as_f32(~mm[0]), qmax = as_f32(mm[1]);
   if (!(qmin < qmax)) return;  // constant cH^2: Otsu early-out, no histogram (block-uniform)
-  s_h[tid] = 0;
+  const HistBins hb(qmin, qmax);
+  {
+    uint4* z = (uint4*)s_cnt;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[tid + 256 * i] = make_uint4(0u, 0u, 0u, 0u);
+    s_edge[tid] = hb.edge(tid);
+    if (tid < 8) s_edge[256 + tid] = __builtin_huge_valf();  // edges[256]: the last bin is closed (idx stays 255)
+  }
   __syncthreads();
-  const HistBins bin_of(qmin, qmax);
-  // the four lowest bins hold most of the mass: byte-packed per-lane counters, flushed before overflow
-  unsigned packed = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, since_flush = 0;
-  auto count = [&](int idx) {
-    packed += (idx < 4) ? (1u << (8 * idx)) : 0u;  // branch-free for the bins that hold the mass
-    if (idx >= 4) atomicAdd(&s_h[idx], 1u);
-  };
-  auto flush = [&]() {
-    c0 += packed & 0xFFu; c1 += (packed >> 8) & 0xFFu; c2 += (packed >> 16) & 0xFFu; c3 += packed >> 24;
-    packed = 0;
-    since_flush = 0;
+  const unsigned lane_off = (unsigned)(lane >> 1) * 4u;
+  const unsigned inc = (lane & 1) ? 0x10000u : 1u;
+  const float scale = hb.scale;
+  auto tally = [&](float x) {
+    const float q = x * x;
+    const int i0 = min((int)((q - qmin) * scale), 255);
+    const float e_lo = s_edge[i0], e_hi = s_edge[i0 + 1];
+    const int idx = i0 - (q < e_lo ? 1 : 0) + (q >= e_hi ? 1 : 0);
+    atomicAdd((unsigned*)((char*)s_cnt + ((unsigned)idx * 128u + lane_off)), inc);
   };
   const float* da = a.ws + plane * a.ws_plane_stride + a.da_off;
   const int r0 = blockIdx.x * a.rows_per_block;
-  const int r1 = min(a.h, r0 + a.rows_per_block);
-  // The kernel waits on memory, not on arithmetic: two rows x two 256-column chunks = four independent
-  // 16-byte loads are in flight per lane before the first value is binned (clamped addresses keep the
-  // loads unconditional; what a clamped load returns is not counted).
-  // full (wave-uniform): the 256-column chunk lies inside the row for every lane -- no per-element bounds tests
-  auto tally = [&](const float4& v, int c, bool on, bool full) {
-    if (on) {
-      count(bin_of(v.x * v.x));
-      if (full) {
-        count(bin_of(v.y * v.y));
-        count(bin_of(v.z * v.z));
-        count(bin_of(v.w * v.w));
-      } else {
-        if (c + 1 < a.w) count(bin_of(v.y * v.y));
-        if (c + 2 < a.w) count(bin_of(v.z * v.z));
-        if (c + 3 < a.w) count(bin_of(v.w * v.w));
-      }
-      since_flush += 4;
-    }
-  };
-  for (int r = r0 + wave; r < r1; r += 8) {
-    const bool two = r + 4 < r1;  // wave-uniform
-    const float* rowa = da + (long long)r * a.ld;  // 16-byte aligned, pitch a multiple of 4
-    const float* rowb = da + (long long)(two ? r + 4 : r) * a.ld;
-    for (int c = 4 * lane; c < a.w; c += 8 * 64) {
-      const int c2 = c + 4 * 64;
-      const bool on2 = c2 < a.w;
-      const int c2l = on2 ? c2 : c;
+  const int nrows = min(a.h, r0 + a.rows_per_block) - r0;
+  // ---- full 256-column chunks: item = (row, chunk), dealt round robin to the four waves, kHistLoads at a time ----
+  const int gf = a.w >> 8;
+  const int nitems = nrows * gf;
+  for (int it0 = wave; it0 < nitems; it0 += 4 * kHistLoads) {
+    dsx_f4 v[kHistLoads];
+#pragma unroll
+    for (int k = 0; k < kHistLoads; ++k) {
+      const int it = min(it0 + 4 * k, nitems - 1);  // clamped: what a clamped load returns is not counted
+      const int row = it / gf, g = it - row * gf;   // wave-uniform (scalar unit)
+      const float* p = da + (long long)(r0 + row) * a.ld + 256 * g + 4 * lane;
 #if DSX_NT
-      const dsx_f4 na0 = __builtin_nontemporal_load((const dsx_f4*)(rowa + c)), na1 = __builtin_nontemporal_load((const dsx_f4*)(rowa + c2l));
-      const dsx_f4 nb0 = __builtin_nontemporal_load((const dsx_f4*)(rowb + c)), nb1 = __builtin_nontemporal_load((const dsx_f4*)(rowb + c2l));
-      const float4 va0 = make_float4(na0.x, na0.y, na0.z, na0.w), va1 = make_float4(na1.x, na1.y, na1.z, na1.w);
-      const float4 vb0 = make_float4(nb0.x, nb0.y, nb0.z, nb0.w), vb1 = make_float4(nb1.x, nb1.y, nb1.z, nb1.w);
+      v[k] = __builtin_nontemporal_load((const dsx_f4*)p);
 #else
-      const float4 va0 = *(const float4*)(rowa + c), va1 = *(const float4*)(rowa + c2l);
-      const float4 vb0 = *(const float4*)(rowb + c), vb1 = *(const float4*)(rowb + c2l);
+      v[k] = *(const dsx_f4*)p;
 #endif
-      const int cbase = c - 4 * lane;  // wave-uniform
-      const bool full0 = cbase + 256 <= a.w, full1 = cbase + 512 <= a.w;
-      tally(va0, c, true, full0);
-      tally(va1, c2, on2, full1);
-      tally(vb0, c, two, full0);
-      tally(vb1, c2, two && on2, full1);
-      if (since_flush >= 236) flush();
+    }
+#pragma unroll
+    for (int k = 0; k < kHistLoads; ++k) {
+      if (it0 + 4 * k < nitems) {  // wave-uniform
+        tally(v[k].x); tally(v[k].y); tally(v[k].z); tally(v[k].w);
+      }
     }
   }
-  flush();
-  c0 = __reduce_add_sync(~0ull, c0);
-  c1 = __reduce_add_sync(~0ull, c1);
-  c2 = __reduce_add_sync(~0ull, c2);
-  c3 = __reduce_add_sync(~0ull, c3);
-  if (lane == 0) {
-    if (c0) atomicAdd(&s_h[0], c0);
-    if (c1) atomicAdd(&s_h[1], c1);
-    if (c2) atomicAdd(&s_h[2], c2);
-    if (c3) atomicAdd(&s_h[3], c3);
+  // ---- the last (w mod 256) columns of every row: one value per thread and step ----
+  const int tw = a.w - (gf << 8);
+  for (int e = tid; e < nrows * tw; e += 256) {
+    const int row = e / tw, c = (gf << 8) + (e - row * tw);
+    tally(da[(long long)(r0 + row) * a.ld + c]);
   }
   __syncthreads();
-  const unsigned n = s_h[tid];
+  // bin tid: 32 dwords, read in a rotated order (thread t starts at column t: no two threads of a group on one bank)
+  unsigned n = 0;
+#pragma unroll 8
+  for (int j = 0; j < 32; ++j) {
+    const unsigned v = s_cnt[tid * 32 + ((j + tid) & 31)];
+    n += (v & 0xFFFFu) + (v >> 16);
+  }
   if (n) atomicAdd(&a.hist[((long long)plane * a.L + a.lvl) * 256 + tid], n);
 }
 

@@ -247,5 +247,10 @@ def u16_plane_against_oracle(got, plane, tile_name, shadow_correction, what):
     stats = {"off_by_one": float((d > 0).mean()), "beyond": float(far.mean()), "worst": int(d.max())}
     assert far.mean() <= 2e-3, (what, stats)
     assert (d > 0).mean() < 1e-2, (what, stats)
-    assert d.max() <= max(2, 0.05 * ref.max()), (what, stats)
+    # a flipped coefficient has been seen to move a pixel by 0.32 of its value (fuzz logs): anything
+    # beyond half a pixel value is not a near-threshold decision
+    # (relative to the value BEFORE the dark field was subtracted: the correction leaves tens of counts of a pixel)
+    dark = 0.0 if shadow_correction is None else np.asarray(shadow_correction["darkfield"], dtype=np.float64)
+    stats["worst_rel"] = float((d / np.maximum(ref + dark, 16)).max())
+    assert stats["worst_rel"] <= 0.5, (what, stats)
     return stats
