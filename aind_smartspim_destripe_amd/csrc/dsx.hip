@@ -91,6 +91,7 @@ struct dsx_ctx {
   // DSX_EVALUE instead and clears the word.
   unsigned* h_sticky = nullptr;
   unsigned* d_sticky = nullptr;
+  bool no_fuse_rf = false;  // DSX_NO_FUSE_RF=1: k_rowfilter + k_inv_march instead of k_rowfinal (same bits)
   // DSX_ABLATE environment variable (timing-only switches that return WRONG pixels): read only by a library built
   // with -DDSX_DIAG (tools/build_variant.sh); the product build has no such switch
   int ablate = 0;
@@ -297,6 +298,32 @@ hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStre
   return launch_rowfilter<36>(a, npairs, nb, s);
 }
 
+// Level-1 row filter + final synthesis in one kernel (k_rowfinal): Delta_1 stays in LDS.  Shapes that take it: see the
+// kernel's header.  DSX_NO_FUSE_RF=1 (read by dsx_init) keeps the two kernels: A/B runs and the bit-identity test.
+bool rowfinal_applies(const dsx::Plan& p, const dsx::LevelPlan& lp, int in_dtype, int out_dtype, bool pair_io) {
+  if (!pair_io || in_dtype != DSX_U16 || out_dtype != DSX_U16) return false;
+  const int gf = lp.w >> 8, nt = (lp.w - (gf << 8) + 63) >> 6;
+  const bool plan1 = lp.M == 1026 && lp.K == 0 && lp.npass == 3 && lp.radix[0] == 19 && lp.radix[1] == 9 && lp.radix[2] == 6;
+  return plan1 && gf == 4 && nt == 1 && (lp.w & 1) == 0 && (p.Wout + dsx::kMarchCols - 1) / dsx::kMarchCols <= dsx::kRfWaves;
+}
+
+hipError_t launch_rowfinal(const dsx::RowFinalArgs& a, int nb, hipStream_t s) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto kern = dsx::k_rowfinal<18, 4, 1, 0, 1>;
+  if (!attr_set[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev & 63] = true;
+  }
+  const size_t smem = (size_t)a.r.M * (dsx::kRfWaves + 1) * sizeof(float2);
+  const int np = (a.f.hout + 1) / 2;
+  const dim3 grid((np + dsx::kRfRows - 1) / dsx::kRfRows, nb);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * dsx::kRfWaves), smem, s, a);
+  return hipGetLastError();
+}
+
 // Row segmentation of the marching kernels: enough waves to fill the chip for small cohorts,
 // one segment per strip for large ones (each extra segment re-reads a 4-row halo).
 void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg) {
@@ -346,6 +373,12 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
                       p.lv[0].w >= 16;
   static const bool no_fuse_inv = getenv("DSX_NO_FUSE_INV") && atoi(getenv("DSX_NO_FUSE_INV")) != 0;
   const bool fuse21 = fuse12 && !no_fuse_inv;
+  // uint16 planes whose rows and bases allow 16-byte pixel / result accesses by lane pairs (inv_march_body<.., PAIR>)
+  static const bool no_pair = getenv("DSX_NO_PAIR") && atoi(getenv("DSX_NO_PAIR")) != 0;
+  const bool pair_io = !no_pair && in_dtype == DSX_U16 && (p.W % 8) == 0 && (p.H % 2) == 0 && p.Wout == p.W &&
+                       (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && ((size_t)p.H * p.W * 2) % 16 == 0;
+  // level-1 row filter inside the final kernel (k_rowfinal): not for the staged debug runs, which read Delta_1 back
+  const bool fuse_rf = fuse21 && !ctx->no_fuse_rf && ctx->stop_after == 0 && rowfinal_applies(p, p.lv[0], in_dtype, out_dtype, pair_io);
   // The wide levels (1, 2) hold 94 % of the coefficients; the coarse levels are chains of small launches that
   // leave most of the chip idle.  With the fused forward kernel the wide levels' data is complete early, so
   // their histograms (and, below, their row filters) run on the part's helper stream BESIDE the coarse
@@ -503,6 +536,8 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     DSX_HIP(hipEventRecord(v.ev[2], s));                  // thresholds are known
     DSX_HIP(hipStreamWaitEvent(v.helper, v.ev[2], 0));
   }
+  dsx::RowArgs row1;  // level 1, for k_rowfinal
+  memset(&row1, 0, sizeof(row1));
   for (int l = 0; l < L && l < skip_from; ++l) {
     hipStream_t rs = (split_inv && l < 2) ? v.helper : s;
     if ((skip_row >> l) & 1) continue;
@@ -528,6 +563,10 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.kcut[1] = lp.kcut[1];
     a.inv_M = 1.0f / (float)lp.M;
     a.ablate = ctx->ablate;
+    if (fuse_rf && l == 0) {
+      row1 = a;
+      continue;
+    }
     const int npairs = (lp.h + 1) / 2;
     LaunchScope ls(ctx, KC_ROW);
     DSX_HIP(dispatch_rowfilter(a, npairs, nb, rs));
@@ -620,9 +659,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
       f.hc2 = l2.h; f.wc2 = l2.w; f.ldc2 = l2.lda; f.ldd2 = l2.ld;
       f.has_c2 = (L > 2) ? 1 : 0;
       f.has_c = 1;
-      static const bool no_pair = getenv("DSX_NO_PAIR") && atoi(getenv("DSX_NO_PAIR")) != 0;
-      f.pair_io = (!no_pair && in_dtype == DSX_U16 && (p.W % 8) == 0 && (p.H % 2) == 0 && p.Wout == p.W &&
-                   (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && ((size_t)p.H * p.W * 2) % 16 == 0) ? 1 : 0;
+      f.pair_io = pair_io ? 1 : 0;
       if (f.rows_per_seg & 1) {  // segments start at even level-1 rows
         f.rows_per_seg += 1;
         f.nseg = ((f.hout + 1) / 2 + f.rows_per_seg - 1) / f.rows_per_seg;
@@ -631,7 +668,12 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
     LaunchScope ls(ctx, last ? KC_FINAL : KC_INV);
     static const int inv_wpb = getenv("DSX_INV_WPB") ? atoi(getenv("DSX_INV_WPB")) : 8;
-    if (fused && inv_wpb == 8) {
+    if (fused && fuse_rf) {
+      dsx::RowFinalArgs rf;
+      rf.r = row1;
+      rf.f = f;
+      DSX_HIP(launch_rowfinal(rf, nb, s));
+    } else if (fused && inv_wpb == 8) {
       const dim3 g8((f.nstrips * f.nseg + 7) / 8, nb);
       if (in_dtype == DSX_U16) hipLaunchKernelGGL((dsx::k_inv_march<0, true, 8>), g8, dim3(512), 0, s, f);
       else hipLaunchKernelGGL((dsx::k_inv_march<1, true, 8>), g8, dim3(512), 0, s, f);
@@ -814,6 +856,7 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
   if (const char* ab = getenv("DSX_ABLATE")) c->ablate = atoi(ab);
 #endif
   if (const char* gm = getenv("DSX_GRAPH")) c->graph_mode = atoi(gm) != 0 ? 1 : 0;
+  if (const char* nf = getenv("DSX_NO_FUSE_RF")) c->no_fuse_rf = atoi(nf) != 0;
   if (const char* ns = getenv("DSX_STREAMS")) c->n_streams = std::max(1, std::min(atoi(ns), (int)dsx_ctx::kMaxStreams));
   // DSX_PRIO=p0,p1,...: stream priority per sub-cohort stream (experiment hook; default: all equal)
   int prio[dsx_ctx::kMaxStreams] = {};

@@ -1364,19 +1364,20 @@ constexpr int kRowMaxWaves = 8;  // waves (row pairs) per block; they share one 
 // (the hot shapes get their own instantiation without the per-group guards); -1: taken from a.w.
 // HALO_: 0 = direct transform (K == 0), 1 = periodic halo (K > 0), -1 = decided at run time.
 // PLAN_: compile-time FFT plan (StaticFft), 0 = the pass list of RowArgs.
-template <int CPL, int GF_ = -1, int NT_ = -1, int HALO_ = -1, int PLAN_ = 0>
-__global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void k_rowfilter(RowArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// TO_LDS (k_rowfinal): Delta is not stored to the workspace but left in the wave's FFT buffer as two planar float rows
+// (row 2 pair at float 0, row 2 pair + 1 at float rf_lds_row_b(M)); pairs outside the plane and levels the plane's
+// config does not filter leave rows of zeros there.  The function contains ONE block-wide barrier (twiddle staging)
+// that every wave of the block must reach: it returns (never exits the kernel) on every path.
+__host__ __device__ __forceinline__ constexpr int rf_lds_row_b(int M) { return (M + 1) & ~1; }
+
+template <int CPL, int GF_, int NT_, int HALO_, int PLAN_, bool TO_LDS>
+__device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, float2* buf, int tid, int nthreads, int lane,
+                                             int pair, int plane) {
   const int M = (PLAN_ > 0) ? StaticFft<PLAN_>::M : a.M;
   const int N = a.w, K = (HALO_ == 0) ? 0 : a.K;
   const bool halo = (HALO_ >= 0) ? (HALO_ != 0) : (K > 0);
-  float2* s_tw = dsx_smem;
-  float2* buf = dsx_smem + (long long)M * (1 + wave);
-  const int pair = blockIdx.x * (blockDim.x >> 6) + wave;
   const int npairs = (a.h + 1) >> 1;
   const bool live = pair < npairs;  // (waves past the last pair still help loading the twiddles)
-  const int plane = blockIdx.y;
   const int r0 = live ? 2 * pair : 0;
   const bool has_b = (r0 + 1) < a.h;
   const int cfg = a.cfg[plane];
@@ -1400,10 +1401,11 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
       }
     }
   };
-  if (inactive) {
+  if (!TO_LDS && inactive) {  // (block-uniform: no wave of the block reaches the barrier below)
     zero_rows();
     return;
   }
+  const bool active = live && !inactive;
   const float thr = a.thr[(long long)plane * a.L + a.lvl];
 
   // ---- load both rows; background = masked entries zeroed (filtering.py:195-197) -------------
@@ -1414,7 +1416,7 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   for (int g = 0; g < GV; ++g) {
     ra4[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     rb4[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live && g < gf) {
+    if (active && g < gf) {
       ra4[g] = *(const float4*)(rowa + 256 * g + 4 * lane);
       if (has_b) rb4[g] = *(const float4*)(rowb + 256 * g + 4 * lane);
     }
@@ -1423,14 +1425,24 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   for (int k = 0; k < 4; ++k) {
     rta[k] = 0.f;
     rtb[k] = 0.f;
-    if (live && k < nt && tn + 64 * k < N) {
+    if (active && k < nt && tn + 64 * k < N) {
       rta[k] = rowa[tn + 64 * k];
       if (has_b) rtb[k] = rowb[tn + 64 * k];
     }
   }
-  for (int i = tid; i < M; i += blockDim.x) s_tw[i] = a.tw[i];
+  for (int i = tid; i < M; i += nthreads) s_tw[i] = a.tw[i];
   __syncthreads();  // the only block-wide barrier: afterwards every wave works on its own rows
-  if (!live) return;
+  float* const lds_a = (float*)buf;
+  float* const lds_b = (float*)buf + rf_lds_row_b(M);
+  if (!active) {
+    if (TO_LDS) {
+      for (int n = 2 * lane; n < N; n += 2 * kWave) {  // N is even for the plans that take this path; see k_rowfinal
+        *(float2*)(lds_a + n) = make_float2(0.f, 0.f);
+        *(float2*)(lds_b + n) = make_float2(0.f, 0.f);
+      }
+    }
+    return;
+  }
 
   // Background values (masked entries zeroed, filtering.py:195-197) stay in registers as floats; slots past
   // the row end hold +inf (never below a threshold, never a minimum).
@@ -1622,6 +1634,40 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
   }
 
   // ---- buf = swap(M * LP): row a <- .y, row b <- .x ; Delta = -(1 - mask) LP (filtering.py:215-217)
+  if (TO_LDS) {
+    // every value is read out of the interleaved buffer before the first planar value overwrites it
+    float oa[E], ob[E];
+    for_slots<GV>(gf, nt, [&](int e) {
+      const int n = (e < 4 * GV) ? 256 * (e >> 2) + 4 * lane + (e & 3) : tn + 64 * (e - 4 * GV);
+      oa[e] = 0.f;
+      ob[e] = 0.f;
+      if (e < 4 * GV || n < N) {
+        const float2 y = buf[K + n];
+        oa[e] = ((maska >> e) & (mask_t)1) ? 0.f : -y.y * a.inv_M;
+        ob[e] = (!has_b || ((maskb >> e) & (mask_t)1)) ? 0.f : -y.x * a.inv_M;
+      }
+    });
+    wave_sync();
+#pragma unroll
+    for (int g = 0; g < GV; ++g) {
+      if (g < gf) {
+        const int nb0 = 256 * g + 4 * lane;  // (row b starts 8-byte aligned only: 8-byte stores)
+        *(float2*)(lds_a + nb0) = make_float2(oa[4 * g], oa[4 * g + 1]);
+        *(float2*)(lds_a + nb0 + 2) = make_float2(oa[4 * g + 2], oa[4 * g + 3]);
+        *(float2*)(lds_b + nb0) = make_float2(ob[4 * g], ob[4 * g + 1]);
+        *(float2*)(lds_b + nb0 + 2) = make_float2(ob[4 * g + 2], ob[4 * g + 3]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int n = tn + 64 * k;
+      if (k < nt && n < N) {
+        lds_a[n] = oa[4 * GV + k];
+        lds_b[n] = ob[4 * GV + k];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < GV; ++g) {
     if (g < gf) {
@@ -1654,6 +1700,16 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
       if (has_b) rowb[n] = ((maskb >> e) & (mask_t)1) ? 0.f : -y.x * a.inv_M;
     }
   }
+}
+
+// One wave per pair of rows, kRowMaxWaves pairs per block (they share one twiddle table).
+template <int CPL, int GF_ = -1, int NT_ = -1, int HALO_ = -1, int PLAN_ = 0>
+__global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void k_rowfilter(RowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = (PLAN_ > 0) ? StaticFft<PLAN_>::M : a.M;
+  rf_pair_body<CPL, GF_, NT_, HALO_, PLAN_, false>(a, dsx_smem, dsx_smem + (long long)M * (1 + wave), tid, blockDim.x, lane,
+                                                   blockIdx.x * (blockDim.x >> 6) + wave, blockIdx.y);
 }
 
 // ================================================================================================
@@ -2177,6 +2233,230 @@ __global__ __launch_bounds__(64 * WPB, (FUSE && IN_KIND == 0) ? DSX_INV_MINW : 1
     if (fast) inv_march_body<IN_KIND, true, false>(a, lane, strip, seg, plane);
     else inv_march_body<IN_KIND, false, false>(a, lane, strip, seg, plane);
   }
+}
+
+// ================================================================================================
+// K4 + K5/K6 fused (round 3): level-1 row filter AND final synthesis in one kernel -- Delta_1 never touches HBM.
+//
+// Round 2's chain wrote Delta_1 (4.2 MB per 2048^2 plane) out of k_rowfilter and read it back in the final kernel: 8.4
+// of the 61.6 MB a plane moved, on a chain whose 4-stream mix runs at the HBM ceiling of its access pattern.  Here a
+// block of kRfWaves waves first filters kRfWaves row pairs of cH_1 exactly as k_rowfilter does (rf_pair_body, same
+// code, same bits) but leaves the 2 kRfWaves Delta_1 rows in its FFT buffers (LDS, planar).  After ONE more block
+// barrier the same waves turn into the strips of the final kernel: wave s owns result columns [256 s, 256 s + 256) and
+// runs the 2 kRfWaves - 2 coefficient rows p whose three source rows p .. p + 2 the block holds (the last row pair
+// is filtered again by the next block: + 1 / 7 of the level-1 FFT work, vector instructions the memory-bound mix has
+// to spare).  The c_1 rows come from level 2 (c_2, Delta_2) as in k_inv_march<.., FUSE>, but every lane synthesises
+// the four c_1 columns it consumes itself from level-2 coefficients Q .. Q + 3, Q = 64 s + lane (overlapping 16-byte
+// loads at 4-byte granularity, L2 hits): no LDS ring, no exchange between lanes, nothing but loads, arithmetic and
+// stores in the synthesis phase.  Pixel rows are read and result rows written by lane pairs (16 bytes per lane) as in
+// inv_march_body<.., PAIR>.  The arithmetic of both phases is the unfused chain's, operation for operation: results
+// are bit-identical (tests/test_gpu_parity.py::test_fused_rowfinal_is_bit_identical_to_the_unfused_chain).
+//
+// Shapes: uint16 planes, W % 8 == 0, H even, <= kRfWaves strips (W <= 2048), direct level-1 plan 1026 = 19 * 9 * 6
+// (2048-wide planes).  Everything else takes k_rowfilter + k_inv_march.
+// ================================================================================================
+constexpr int kRfWaves = 8;
+constexpr int kRfRows = 2 * kRfWaves - 2;  // coefficient rows p per block
+
+struct RowFinalArgs {
+  RowArgs r;
+  FinalArgs f;
+};
+
+template <bool SHADE>
+__device__ __forceinline__ void rowfinal_synth(const FinalArgs& a, const float2* smem, int M, int lane, int strip, int plane,
+                                               int p_begin, int p_end, int row0) {
+  constexpr float RL0[6] = DSX_REC_LO;
+  constexpr float RH0[6] = DSX_REC_HI;
+  constexpr float KS = 1.44269504088896340736f;  // the result feeds exp2(): the axis-0 taps of level 1 carry log2(e)
+  constexpr float RL[6] = {RL0[0] * KS, RL0[1] * KS, RL0[2] * KS, RL0[3] * KS, RL0[4] * KS, RL0[5] * KS};
+  constexpr float RH[6] = {RH0[0] * KS, RH0[1] * KS, RH0[2] * KS, RH0[3] * KS, RH0[4] * KS, RH0[5] * KS};
+  const int x0 = kMarchCols * strip + 4 * lane;
+  const int xl = min(x0, a.W - 4);  // lanes right of the plane: clamped (valid) addresses, results never stored
+  const int ql = xl >> 1;           // first Delta_1 / c_1 column of the lane
+  const bool odd_lane = (lane & 1) != 0;
+  const int xb = min(kMarchCols * strip + 8 * (lane >> 1), a.W - 8);  // first column of the lane pair (clamped)
+  const __amdgpu_buffer_rsrc_t rs_img = dsx_rsrc((const char*)a.img + plane * a.img_plane_stride * 2);
+  const __amdgpu_buffer_rsrc_t rs_out = dsx_rsrc((const char*)a.out + plane * a.out_plane_stride * 2);
+  const unsigned vo_pair0 = (unsigned)xb * 2u, vo_pair = vo_pair0 + (odd_lane ? (unsigned)a.W * 2u : 0u);
+  const unsigned vo_pair_out = (unsigned)xb * 2u + (odd_lane ? (unsigned)a.wout * 2u : 0u);
+  const int xs = min(x0, max(a.wout - 4, 0));
+  const __amdgpu_buffer_rsrc_t rs_dark = dsx_rsrc(SHADE ? a.dark : a.ws), rs_flat = dsx_rsrc(SHADE ? a.flat : a.ws);
+  const unsigned vo_shade = (unsigned)xs * 4u;
+  const bool shade_vec = SHADE && (a.wout & 3) == 0 && (a.dark_ld & 3) == 0 && a.wout >= 4 &&
+                         (((uintptr_t)a.dark | (uintptr_t)a.flat) & 15) == 0;
+
+  // ---- level 2 -> c_1, per lane: coefficients Q .. Q + 3 give c_1 columns 2 Q .. 2 Q + 3 = ql .. ql + 3 -------------
+  const int Q = ql >> 1;
+  const float* c2base = a.ws + plane * a.ws_plane_stride + a.c2_off;
+  const float* d2base = a.ws + plane * a.ws_plane_stride + a.d2_off;
+  const __amdgpu_buffer_rsrc_t rs_c2 = dsx_rsrc(c2base), rs_d2 = dsx_rsrc(d2base);
+  const unsigned vo_2 = (unsigned)Q * 4u;
+  auto l2_load = [&](int P2) {
+    FinalRawC r;
+    r.c01 = r.c23 = make_float2(0.f, 0.f);
+    const int pr = min(P2, a.hc2 - 1);  // rows past the end only feed c_1 rows that are never used
+    if (a.has_c2) {
+      const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_c2, vo_2, (unsigned)(pr * a.ldc2) * 4u, 0);
+      r.c01 = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+      r.c23 = make_float2(__uint_as_float(u.z), __uint_as_float(u.w));
+    }
+    const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_d2, vo_2, (unsigned)(pr * a.ldd2) * 4u, 0);
+    r.d01 = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+    r.d23 = make_float2(__uint_as_float(u.z), __uint_as_float(u.w));
+    return r;
+  };
+  dsx_f2 A2[3][2], D2[3][2];
+  FinalRawC n2;
+  dsx_f2 c1e[2], c1o[2];  // c_1 rows 2 P, 2 P + 1 of the last level-2 step (columns ql .. ql + 3 as packed pairs)
+  int next_P = p_begin >> 1, c1_ready = p_begin;  // c_1 rows < c1_ready have been produced (p_begin is even)
+  {
+    const FinalRawC w0 = l2_load(next_P), w1 = l2_load(next_P + 1);
+    final_xsynth(w0.c01, w0.c23, A2[0]);
+    final_xsynth(w0.d01, w0.d23, D2[0]);
+    final_xsynth(w1.c01, w1.c23, A2[1]);
+    final_xsynth(w1.d01, w1.d23, D2[1]);
+    n2 = l2_load(next_P + 2);
+  }
+  auto l2_step = [&]() {  // level-2 rows P .. P + 2 -> c_1 rows 2 P, 2 P + 1 (plain taps: a log-image correction)
+    final_xsynth(n2.c01, n2.c23, A2[2]);
+    final_xsynth(n2.d01, n2.d23, D2[2]);
+    n2 = l2_load(next_P + 3);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      c1e[h] = pk_dot6(A2[0][h], RL0[4], A2[1][h], RL0[2], A2[2][h], RL0[0], D2[0][h], RH0[4], D2[1][h], RH0[2],
+                       D2[2][h], RH0[0]);
+      c1o[h] = pk_dot6(A2[0][h], RL0[5], A2[1][h], RL0[3], A2[2][h], RL0[1], D2[0][h], RH0[5], D2[1][h], RH0[3],
+                       D2[2][h], RH0[1]);
+      A2[0][h] = A2[1][h]; A2[1][h] = A2[2][h];
+      D2[0][h] = D2[1][h]; D2[1][h] = D2[2][h];
+    }
+    ++next_P;
+    c1_ready += 2;
+  };
+  // row-synthesised c_1 row p (rows are asked for in increasing order, each once)
+  auto c1_row = [&](int p, dsx_f2 (&out)[2]) {
+    if (c1_ready <= p) l2_step();  // wave-uniform
+    const dsx_f2 lo = (p & 1) ? c1o[0] : c1e[0], hi = (p & 1) ? c1o[1] : c1e[1];
+    final_xsynth(make_float2(lo.x, lo.y), make_float2(hi.x, hi.y), out);
+  };
+  // row-synthesised Delta_1 row r out of the block's FFT buffers (planar rows, see rf_pair_body<.., TO_LDS>)
+  auto d1_row = [&](int r, dsx_f2 (&out)[2]) {
+    const int rr = r - row0;  // 0 .. 2 kRfWaves - 1 (wave-uniform)
+    const float* row = (const float*)(smem + (long long)M * (1 + (rr >> 1))) + ((rr & 1) ? rf_lds_row_b(M) : 0) + ql;
+    const float2 lo = *(const float2*)row, hi = *(const float2*)(row + 2);
+    final_xsynth(lo, hi, out);
+  };
+  auto issue_i = [&](int gy) {  // 16 bytes of pixel row gy + (lane & 1), one load per row pair
+    const int ge = min(gy, a.H - 1);                          // wave-uniform
+    const unsigned vo = (ge + 1 < a.H) ? vo_pair : vo_pair0;  // the odd lane's row exists (scalar condition)
+    const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_img, vo, (unsigned)(ge * a.W) * 2u, kBufNT);
+    return make_uint4(u.x, u.y, u.z, u.w);
+  };
+
+  dsx_f2 A[3][2], D[3][2];  // windows: rows p, p + 1, p + 2
+  uint4 ni[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) ni[r] = issue_i(2 * (p_begin + r));
+  c1_row(p_begin, A[0]);
+  d1_row(p_begin, D[0]);
+  c1_row(p_begin + 1, A[1]);
+  d1_row(p_begin + 1, D[1]);
+
+  auto px_row = [&](int gy, uint2 u, const dsx_f2 (&c0p)[2], unsigned (&pk)[2]) {
+    const float c0[4] = {c0p[0].x, c0p[0].y, c0p[1].x, c0p[1].y};
+    const float px[4] = {(float)(u.x & 0xFFFFu), (float)(u.x >> 16), (float)(u.y & 0xFFFFu), (float)(u.y >> 16)};
+    float r[4];
+    if (SHADE) {
+      float dk[4], fl[4];
+      const int gys = min(gy, a.hout - 1);
+      if (shade_vec) {
+        const dsx_u32x4 d4 = __builtin_amdgcn_raw_buffer_load_b128(rs_dark, vo_shade, (unsigned)(gys * a.dark_ld) * 4u, 0);
+        const dsx_u32x4 f4 = __builtin_amdgcn_raw_buffer_load_b128(rs_flat, vo_shade, (unsigned)(gys * a.wout) * 4u, 0);
+        dk[0] = __uint_as_float(d4.x); dk[1] = __uint_as_float(d4.y); dk[2] = __uint_as_float(d4.z); dk[3] = __uint_as_float(d4.w);
+        fl[0] = __uint_as_float(f4.x); fl[1] = __uint_as_float(f4.y); fl[2] = __uint_as_float(f4.z); fl[3] = __uint_as_float(f4.w);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int gx = min(x0 + e, a.wout - 1);
+          dk[e] = a.dark[(long long)gys * a.dark_ld + gx];
+          fl[e] = a.flat[(long long)gys * a.wout + gx];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = final_px<SHADE>(a, c0[e], px[e], dk[e], fl[e]);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const dsx_f2 one = {1.0f, 1.0f};
+        const dsx_f2 x1 = dsx_f2{px[2 * h], px[2 * h + 1]} + one;
+        const dsx_f2 ex = {__builtin_amdgcn_exp2f(c0[2 * h]), __builtin_amdgcn_exp2f(c0[2 * h + 1])};
+        const dsx_f2 v = pk_fma(x1, ex, one);
+        r[2 * h] = v.x;
+        r[2 * h + 1] = v.y;
+      }
+    }
+    pk[0] = pack_u16_sat(r[0], r[1]);
+    pk[1] = pack_u16_sat(r[2], r[3]);
+  };
+  // one coefficient row p -> result rows 2p, 2p + 1; (A0, A1, A2) = window rows p, p + 1, p + 2
+  auto step = [&](int p, const uint4& ri, dsx_f2 (&A0)[2], dsx_f2 (&A1)[2], dsx_f2 (&A2w)[2], dsx_f2 (&D0)[2],
+                  dsx_f2 (&D1)[2], dsx_f2 (&D2w)[2]) {
+    c1_row(p + 2, A2w);
+    d1_row(p + 2, D2w);
+    dsx_f2 even[2], odd[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      even[h] = pk_dot6(A0[h], RL[4], A1[h], RL[2], A2w[h], RL[0], D0[h], RH[4], D1[h], RH[2], D2w[h], RH[0]);
+      odd[h] = pk_dot6(A0[h], RL[5], A1[h], RL[3], A2w[h], RL[1], D0[h], RH[5], D1[h], RH[3], D2w[h], RH[1]);
+    }
+    // ri: this lane's 16 bytes of pixel row 2p + (lane & 1); the own half of the own row stays, the other row's
+    // own half comes from the neighbour (see inv_march_body<.., PAIR>)
+    const unsigned sx = odd_lane ? ri.x : ri.z, sy = odd_lane ? ri.y : ri.w;
+    const unsigned gx = swap_adjacent(sx), gyv = swap_adjacent(sy);
+    const uint2 r0 = odd_lane ? make_uint2(gx, gyv) : make_uint2(ri.x, ri.y);  // row 2p, own 4 columns
+    const uint2 r1 = odd_lane ? make_uint2(ri.z, ri.w) : make_uint2(gx, gyv);  // row 2p + 1
+    unsigned pe[2], po[2];
+    px_row(2 * p, r0, even, pe);
+    px_row(2 * p + 1, r1, odd, po);
+    const unsigned tx = swap_adjacent(odd_lane ? pe[0] : po[0]), ty = swap_adjacent(odd_lane ? pe[1] : po[1]);
+    dsx_u32x4 o4;
+    o4.x = odd_lane ? tx : pe[0];
+    o4.y = odd_lane ? ty : pe[1];
+    o4.z = odd_lane ? po[0] : tx;
+    o4.w = odd_lane ? po[1] : ty;
+    const int gyl = 2 * p + (odd_lane ? 1 : 0);
+    if (gyl < a.hout && x0 < a.wout)
+      __builtin_amdgcn_raw_buffer_store_b128(o4, rs_out, vo_pair_out, (unsigned)(2 * p * a.wout) * 2u, kBufNT);
+  };
+  for (int p = p_begin; p < p_end; p += 3) {
+    const bool more = p + 3 < p_end;  // wave-uniform
+    step(p, ni[0], A[0], A[1], A[2], D[0], D[1], D[2]);
+    if (more) ni[0] = issue_i(2 * (p + 3));
+    if (p + 1 < p_end) step(p + 1, ni[1], A[1], A[2], A[0], D[1], D[2], D[0]);
+    if (more) ni[1] = issue_i(2 * (p + 4));
+    if (p + 2 < p_end) step(p + 2, ni[2], A[2], A[0], A[1], D[2], D[0], D[1]);
+    if (more) ni[2] = issue_i(2 * (p + 5));
+  }
+}
+
+// PLAN_ / CPL / GF_ / NT_ / HALO_ as in k_rowfilter; the block's row pairs are [kRfWaves - 1) * blockIdx.x + wave
+template <int CPL, int GF_, int NT_, int HALO_, int PLAN_>
+__global__ __launch_bounds__(64 * kRfWaves, 4) void k_rowfinal(RowFinalArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int M = StaticFft<PLAN_>::M;
+  const int plane = blockIdx.y;
+  const int pair0 = (kRfWaves - 1) * blockIdx.x;  // first row pair of the block; its coefficient rows start at 2 pair0
+  rf_pair_body<CPL, GF_, NT_, HALO_, PLAN_, true>(a.r, dsx_smem, dsx_smem + (long long)M * (1 + wave), tid, 64 * kRfWaves, lane,
+                                                  pair0 + wave, plane);
+  __syncthreads();  // all 2 kRfWaves Delta_1 rows of the block are in LDS
+  const int np = (a.f.hout + 1) >> 1;
+  const int p_begin = 2 * pair0, p_end = min(np, p_begin + kRfRows);
+  if (wave >= a.f.nstrips || p_begin >= p_end) return;
+  if (a.f.flat != nullptr) rowfinal_synth<true>(a.f, dsx_smem, M, lane, wave, plane, p_begin, p_end, 2 * pair0);
+  else rowfinal_synth<false>(a.f, dsx_smem, M, lane, wave, plane, p_begin, p_end, 2 * pair0);
 }
 
 }  // namespace dsx

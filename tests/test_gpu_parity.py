@@ -667,6 +667,44 @@ def test_graph_replay_is_bit_identical_to_eager_launches(monkeypatch):
         e.close()
 
 
+def test_fused_rowfinal_is_bit_identical_to_the_unfused_chain(monkeypatch):
+    """2048-wide uint16 planes run the level-1 row filter INSIDE the final kernel (k_rowfinal: Delta_1 stays in LDS, every
+    lane synthesises its own c_1 columns from level 2).  Same arithmetic, operation for operation: the result must equal
+    the chain with k_rowfilter + k_inv_march (DSX_NO_FUSE_RF=1) bit for bit -- unsplit cohort (helper stream), a cohort
+    split over the four streams, with and without the shading epilogue, a plane of constant rows, a plane with the
+    cells config, and a short plane (2048 wide, 200 high: the last block is partial)."""
+    w = 2048
+    for h, n, shading in ((2048, 72, False), (2048, 20, True), (200, 40, False)):
+        bank = synth.synthetic_bank(6, h, w)
+        flatp = np.full((h, w), 300, np.uint16)
+        rows = np.repeat((100 + 50 * np.arange(h, dtype=np.uint16) % 7)[:, None], w, axis=1).astype(np.uint16)
+        stack = np.concatenate([bank, flatp[None], rows[None], synth.synthetic_stack(n - 8, h, w, bank=bank)])
+        flat = dark = None
+        if shading:
+            yy, xx = np.mgrid[0:h, 0:w]
+            flat = (1.0 - 0.15 * (((yy - h / 2.0) / (h / 2.0)) ** 2 + ((xx - w / 2.0) / (w / 2.0)) ** 2)).astype(np.float32)
+            dark = np.full((h, w), 100.0, np.float32)
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("DSX_NO_FUSE_RF", mode)
+            e = eng_mod.DestripeEngine(0)
+            try:
+                e.plan(h, w, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT, max_batch=n,
+                       flatfield=flat, darkfield=dark)
+                small = e.run(stack[:8], out_dtype=np.uint16)            # one part, helper stream
+                big, cfg = e.run(stack, out_dtype=np.uint16, return_cfg=True)
+                res[mode] = (small, big, cfg)
+            finally:
+                e.close()
+        assert res["0"][2].sum() > 0  # some planes took the cells config
+        for a, b in zip(res["0"], res["1"]):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b), err_msg=str((h, n, shading)))
+        if h == 2048 and not shading:  # and the reference: plane 1 of the stack against the oracle
+            ref = orc.filter_stripes(stack[1], "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT)
+            d = np.abs(res["0"][1][1].astype(np.int64) - ref.astype(np.uint16).astype(np.int64))
+            assert d.max() <= 1
+
+
 def test_timing_switches_do_nothing_in_the_product_build(monkeypatch):
     """The timing-only switches of the measurement builds (DSX_ABLATE, DSX_SKIP_HIST / _ROW / _COARSE: kernels skip a phase
     or a launch and return WRONG pixels) are compiled in under -DDSX_DIAG only (tools/build_variant.sh).  The library the
