@@ -409,7 +409,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.rows_per_block = std::max(1, std::min(hist_rows, 256));  // (16-bit per-lane counters: see k_hist)
     dim3 grid((lp.h + a.rows_per_block - 1) / a.rows_per_block, nb);
     LaunchScope ls(ctx, KC_HIST);
-    hipLaunchKernelGGL(dsx::k_hist, grid, dim3(256), 0, hs, a);
+    hipLaunchKernelGGL(dsx::k_hist, grid, dim3(64 * dsx::kHistWaves), 0, hs, a);
     DSX_HIP(hipGetLastError());
     return DSX_OK;
   };

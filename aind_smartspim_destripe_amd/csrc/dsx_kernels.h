@@ -893,11 +893,13 @@ struct HistBins {
 //     idx = i0 - (q < e_lo) + (q >= e_hi)       lanes read the same pair: broadcast, no bank conflict)
 // which is numpy's estimate-then-correct rule with the correction always applied (the estimate is within 1e-4 bins,
 // the correction moves it by at most one), and one conflict-free LDS atomic: every lane owns a 16-bit counter per bin
-// (256 bins x 32 dwords, lane pair per dword, the four waves of the block share them -- at most 4 x the values of a
-// thread, far below 65536).  10 vector + 2 LDS instructions per value; no data-dependent branch.
+// (256 bins x 32 dwords, lane pair per dword, the kHistWaves waves of the block share them -- at most kHistWaves x the
+// values of a thread, far below 65536).  10 vector + 2 LDS instructions per value; no data-dependent branch.
 constexpr int kHistLoads = 8;  // 16-byte loads in flight per lane
 
-__global__ __launch_bounds__(256) void k_hist(HistArgs a) {
+constexpr int kHistWaves = 8;  // waves per block: they share one 32 KB counter array (LDS is what the 4-stream mix runs short of)
+
+__global__ __launch_bounds__(64 * kHistWaves) void k_hist(HistArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned s_cnt[256 * 32];
   __shared__ float s_edge[264];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -910,9 +912,9 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
   {
     uint4* z = (uint4*)s_cnt;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) z[tid + 256 * i] = make_uint4(0u, 0u, 0u, 0u);
-    s_edge[tid] = hb.edge(tid);
-    if (tid < 8) s_edge[256 + tid] = __builtin_huge_valf();  // edges[256]: the last bin is closed (idx stays 255)
+    for (int i = 0; i < 2048 / (64 * kHistWaves); ++i) z[tid + 64 * kHistWaves * i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 256) s_edge[tid] = hb.edge(tid);
+    else if (tid < 264) s_edge[tid] = __builtin_huge_valf();  // edges[256]: the last bin is closed (idx stays 255)
   }
   __syncthreads();
   const unsigned lane_off = (unsigned)(lane >> 1) * 4u;
@@ -931,11 +933,11 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
   // ---- full 256-column chunks: item = (row, chunk), dealt round robin to the four waves, kHistLoads at a time ----
   const int gf = a.w >> 8;
   const int nitems = nrows * gf;
-  for (int it0 = wave; it0 < nitems; it0 += 4 * kHistLoads) {
+  for (int it0 = wave; it0 < nitems; it0 += kHistWaves * kHistLoads) {
     dsx_f4 v[kHistLoads];
 #pragma unroll
     for (int k = 0; k < kHistLoads; ++k) {
-      const int it = min(it0 + 4 * k, nitems - 1);  // clamped: what a clamped load returns is not counted
+      const int it = min(it0 + kHistWaves * k, nitems - 1);  // clamped: what a clamped load returns is not counted
       const int row = it / gf, g = it - row * gf;   // wave-uniform (scalar unit)
       const float* p = da + (long long)(r0 + row) * a.ld + 256 * g + 4 * lane;
 #if DSX_NT
@@ -946,26 +948,28 @@ __global__ __launch_bounds__(256) void k_hist(HistArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < kHistLoads; ++k) {
-      if (it0 + 4 * k < nitems) {  // wave-uniform
+      if (it0 + kHistWaves * k < nitems) {  // wave-uniform
         tally(v[k].x); tally(v[k].y); tally(v[k].z); tally(v[k].w);
       }
     }
   }
   // ---- the last (w mod 256) columns of every row: one value per thread and step ----
   const int tw = a.w - (gf << 8);
-  for (int e = tid; e < nrows * tw; e += 256) {
+  for (int e = tid; e < nrows * tw; e += 64 * kHistWaves) {
     const int row = e / tw, c = (gf << 8) + (e - row * tw);
     tally(da[(long long)(r0 + row) * a.ld + c]);
   }
   __syncthreads();
   // bin tid: 32 dwords, read in a rotated order (thread t starts at column t: no two threads of a group on one bank)
-  unsigned n = 0;
+  if (tid < 256) {
+    unsigned n = 0;
 #pragma unroll 8
-  for (int j = 0; j < 32; ++j) {
-    const unsigned v = s_cnt[tid * 32 + ((j + tid) & 31)];
-    n += (v & 0xFFFFu) + (v >> 16);
+    for (int j = 0; j < 32; ++j) {
+      const unsigned v = s_cnt[tid * 32 + ((j + tid) & 31)];
+      n += (v & 0xFFFFu) + (v >> 16);
+    }
+    if (n) atomicAdd(&a.hist[((long long)plane * a.L + a.lvl) * 256 + tid], n);
   }
-  if (n) atomicAdd(&a.hist[((long long)plane * a.L + a.lvl) * 256 + tid], n);
 }
 
 // ================================================================================================
@@ -2263,9 +2267,16 @@ struct RowFinalArgs {
   FinalArgs f;
 };
 
-template <bool SHADE>
+// Loads of the synthesis phase that do not depend on Delta_1: issued BEFORE the block barrier between the two phases, so
+// that a wave that is done with its row pair has its first pixel rows and level-2 rows in flight while it waits.
+struct RowFinalPre {
+  uint4 ni[2];         // pixel rows of the first two steps (a third costs the registers that make the kernel spill)
+
+};
+
+template <bool SHADE, bool PREFETCH_ONLY = false>
 __device__ __forceinline__ void rowfinal_synth(const FinalArgs& a, const float2* smem, int M, int lane, int strip, int plane,
-                                               int p_begin, int p_end, int row0) {
+                                               int p_begin, int p_end, int row0, RowFinalPre& pre) {
   constexpr float RL0[6] = DSX_REC_LO;
   constexpr float RH0[6] = DSX_REC_HI;
   constexpr float KS = 1.44269504088896340736f;  // the result feeds exp2(): the axis-0 taps of level 1 carry log2(e)
@@ -2306,18 +2317,28 @@ __device__ __forceinline__ void rowfinal_synth(const FinalArgs& a, const float2*
     r.d23 = make_float2(__uint_as_float(u.z), __uint_as_float(u.w));
     return r;
   };
-  dsx_f2 A2[3][2], D2[3][2];
-  FinalRawC n2;
-  dsx_f2 c1e[2], c1o[2];  // c_1 rows 2 P, 2 P + 1 of the last level-2 step (columns ql .. ql + 3 as packed pairs)
+  auto issue_i = [&](int gy) {  // 16 bytes of pixel row gy + (lane & 1), one load per row pair
+    const int ge = min(gy, a.H - 1);                          // wave-uniform
+    const unsigned vo = (ge + 1 < a.H) ? vo_pair : vo_pair0;  // the odd lane's row exists (scalar condition)
+    const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_img, vo, (unsigned)(ge * a.W) * 2u, kBufNT);
+    return make_uint4(u.x, u.y, u.z, u.w);
+  };
   int next_P = p_begin >> 1, c1_ready = p_begin;  // c_1 rows < c1_ready have been produced (p_begin is even)
+  if (PREFETCH_ONLY) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) pre.ni[r] = issue_i(2 * (p_begin + r));
+    return;
+  }
+  dsx_f2 A2[3][2], D2[3][2];
+  dsx_f2 c1e[2], c1o[2];  // c_1 rows 2 P, 2 P + 1 of the last level-2 step (columns ql .. ql + 3 as packed pairs)
   {
     const FinalRawC w0 = l2_load(next_P), w1 = l2_load(next_P + 1);
     final_xsynth(w0.c01, w0.c23, A2[0]);
     final_xsynth(w0.d01, w0.d23, D2[0]);
     final_xsynth(w1.c01, w1.c23, A2[1]);
     final_xsynth(w1.d01, w1.d23, D2[1]);
-    n2 = l2_load(next_P + 2);
   }
+  FinalRawC n2 = l2_load(next_P + 2);
   auto l2_step = [&]() {  // level-2 rows P .. P + 2 -> c_1 rows 2 P, 2 P + 1 (plain taps: a log-image correction)
     final_xsynth(n2.c01, n2.c23, A2[2]);
     final_xsynth(n2.d01, n2.d23, D2[2]);
@@ -2347,17 +2368,9 @@ __device__ __forceinline__ void rowfinal_synth(const FinalArgs& a, const float2*
     const float2 lo = *(const float2*)row, hi = *(const float2*)(row + 2);
     final_xsynth(lo, hi, out);
   };
-  auto issue_i = [&](int gy) {  // 16 bytes of pixel row gy + (lane & 1), one load per row pair
-    const int ge = min(gy, a.H - 1);                          // wave-uniform
-    const unsigned vo = (ge + 1 < a.H) ? vo_pair : vo_pair0;  // the odd lane's row exists (scalar condition)
-    const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_img, vo, (unsigned)(ge * a.W) * 2u, kBufNT);
-    return make_uint4(u.x, u.y, u.z, u.w);
-  };
 
   dsx_f2 A[3][2], D[3][2];  // windows: rows p, p + 1, p + 2
-  uint4 ni[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) ni[r] = issue_i(2 * (p_begin + r));
+  uint4 ni[3] = {pre.ni[0], pre.ni[1], issue_i(2 * (p_begin + 2))};
   c1_row(p_begin, A[0]);
   d1_row(p_begin, D[0]);
   c1_row(p_begin + 1, A[1]);
@@ -2451,12 +2464,17 @@ __global__ __launch_bounds__(64 * kRfWaves, 4) void k_rowfinal(RowFinalArgs a) {
   const int pair0 = (kRfWaves - 1) * blockIdx.x;  // first row pair of the block; its coefficient rows start at 2 pair0
   rf_pair_body<CPL, GF_, NT_, HALO_, PLAN_, true>(a.r, dsx_smem, dsx_smem + (long long)M * (1 + wave), tid, 64 * kRfWaves, lane,
                                                   pair0 + wave, plane);
-  __syncthreads();  // all 2 kRfWaves Delta_1 rows of the block are in LDS
   const int np = (a.f.hout + 1) >> 1;
   const int p_begin = 2 * pair0, p_end = min(np, p_begin + kRfRows);
-  if (wave >= a.f.nstrips || p_begin >= p_end) return;
-  if (a.f.flat != nullptr) rowfinal_synth<true>(a.f, dsx_smem, M, lane, wave, plane, p_begin, p_end, 2 * pair0);
-  else rowfinal_synth<false>(a.f, dsx_smem, M, lane, wave, plane, p_begin, p_end, 2 * pair0);
+  const bool synth = wave < a.f.nstrips && p_begin < p_end;  // wave-uniform
+  RowFinalPre pre;
+  asm volatile("" ::: "memory");  // keep the prefetch loads (and their registers) out of the row-filter phase
+  __builtin_amdgcn_sched_barrier(0);
+  if (synth) rowfinal_synth<false, true>(a.f, dsx_smem, M, lane, wave, plane, p_begin, p_end, 2 * pair0, pre);
+  __syncthreads();  // all 2 kRfWaves Delta_1 rows of the block are in LDS
+  if (!synth) return;
+  if (a.f.flat != nullptr) rowfinal_synth<true>(a.f, dsx_smem, M, lane, wave, plane, p_begin, p_end, 2 * pair0, pre);
+  else rowfinal_synth<false>(a.f, dsx_smem, M, lane, wave, plane, p_begin, p_end, 2 * pair0, pre);
 }
 
 }  // namespace dsx
