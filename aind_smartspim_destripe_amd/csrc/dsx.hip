@@ -92,6 +92,7 @@ struct dsx_ctx {
   unsigned* h_sticky = nullptr;
   unsigned* d_sticky = nullptr;
   bool no_fuse_rf = false;  // DSX_NO_FUSE_RF=1: k_rowfilter + k_inv_march instead of k_rowfinal (same bits)
+  bool fuse_rf_wide = false;  // DSX_FUSE_RF_WIDE=1: k_rowfinal for 2000- / 1800-wide planes too (slower there; rowfinal_plan)
   // DSX_ABLATE environment variable (timing-only switches that return WRONG pixels): read only by a library built
   // with -DDSX_DIAG (tools/build_variant.sh); the product build has no such switch
   int ablate = 0;
@@ -300,18 +301,31 @@ hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStre
 
 // Level-1 row filter + final synthesis in one kernel (k_rowfinal): Delta_1 stays in LDS.  Shapes that take it: see the
 // kernel's header.  DSX_NO_FUSE_RF=1 (read by dsx_init) keeps the two kernels: A/B runs and the bit-identity test.
-bool rowfinal_applies(const dsx::Plan& p, const dsx::LevelPlan& lp, int in_dtype, int out_dtype, bool pair_io) {
-  if (!pair_io || in_dtype != DSX_U16 || out_dtype != DSX_U16) return false;
+// Returns the StaticFft plan id of the instantiation (1, 3, 4) or 0.
+int rowfinal_plan(const dsx::Plan& p, const dsx::LevelPlan& lp, int in_dtype, int out_dtype, bool pair_io, bool wide) {
+  if (!pair_io || in_dtype != DSX_U16 || out_dtype != DSX_U16) return 0;
+  if ((lp.w & 1) != 0 || (p.Wout + dsx::kMarchCols - 1) / dsx::kMarchCols > dsx::kRfWaves) return 0;
   const int gf = lp.w >> 8, nt = (lp.w - (gf << 8) + 63) >> 6;
-  const bool plan1 = lp.M == 1026 && lp.K == 0 && lp.npass == 3 && lp.radix[0] == 19 && lp.radix[1] == 9 && lp.radix[2] == 6;
-  return plan1 && gf == 4 && nt == 1 && (lp.w & 1) == 0 && (p.Wout + dsx::kMarchCols - 1) / dsx::kMarchCols <= dsx::kRfWaves;
+  auto plan_is = [&](int m, int r0, int r1, int r2) {
+    return lp.M == m && lp.npass == 3 && lp.radix[0] == r0 && lp.radix[1] == r1 && lp.radix[2] == r2;
+  };
+  // wide (DSX_FUSE_RF_WIDE=1, read by dsx_init; OFF by default): the embedded plans of 2000- and 1800-wide planes.  Their
+  // FFT buffers are 16 KB per wave: one 8-wave block per CU, the two phases of a block cannot hide behind another
+  // block's, and the fused kernel LOSES 10-12 % against k_rowfilter + k_inv_march there (1600 x 2000: 53.8 k against
+  // 59.8 k planes/s, 1800^2: 54.8 k against 62.8 k; profiles/r3_fused_rowfinal_ab.txt).  Bit-identical all the same
+  // (tests/test_gpu_parity.py::test_fused_rowfinal_is_bit_identical_to_the_unfused_chain runs them with the switch on).
+  if (gf == 4 && nt == 1 && lp.K == 0 && plan_is(1026, 19, 9, 6)) return 1;
+  if (wide && lp.K > 0 && gf == 3 && nt == 4 && plan_is(2048, 16, 16, 8)) return 3;
+  if (wide && lp.K > 0 && gf == 3 && nt == 3 && plan_is(1815, 15, 11, 11)) return 4;
+  return 0;
 }
 
-hipError_t launch_rowfinal(const dsx::RowFinalArgs& a, int nb, hipStream_t s) {
+template <int CPL, int GF, int NT, int HALO, int PLAN>
+hipError_t launch_rowfinal_t(const dsx::RowFinalArgs& a, int nb, hipStream_t s) {
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  auto kern = dsx::k_rowfinal<18, 4, 1, 0, 1>;
+  auto kern = dsx::k_rowfinal<CPL, GF, NT, HALO, PLAN>;
   if (!attr_set[dev & 63]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -322,6 +336,13 @@ hipError_t launch_rowfinal(const dsx::RowFinalArgs& a, int nb, hipStream_t s) {
   const dim3 grid((np + dsx::kRfRows - 1) / dsx::kRfRows, nb);
   hipLaunchKernelGGL(kern, grid, dim3(64 * dsx::kRfWaves), smem, s, a);
   return hipGetLastError();
+}
+
+hipError_t launch_rowfinal(int plan, const dsx::RowFinalArgs& a, int nb, hipStream_t s) {
+  if (plan == 1) return launch_rowfinal_t<18, 4, 1, 0, 1>(a, nb, s);
+  if (plan == 3) return launch_rowfinal_t<36, 3, 4, 1, 3>(a, nb, s);
+  if (plan == 4) return launch_rowfinal_t<36, 3, 3, 1, 4>(a, nb, s);
+  return hipErrorInvalidValue;
 }
 
 // Row segmentation of the marching kernels: enough waves to fill the chip for small cohorts,
@@ -378,7 +399,8 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   const bool pair_io = !no_pair && in_dtype == DSX_U16 && (p.W % 8) == 0 && (p.H % 2) == 0 && p.Wout == p.W &&
                        (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && ((size_t)p.H * p.W * 2) % 16 == 0;
   // level-1 row filter inside the final kernel (k_rowfinal): not for the staged debug runs, which read Delta_1 back
-  const bool fuse_rf = fuse21 && !ctx->no_fuse_rf && ctx->stop_after == 0 && rowfinal_applies(p, p.lv[0], in_dtype, out_dtype, pair_io);
+  const int rf_plan = (fuse21 && !ctx->no_fuse_rf && ctx->stop_after == 0) ? rowfinal_plan(p, p.lv[0], in_dtype, out_dtype, pair_io, ctx->fuse_rf_wide) : 0;
+  const bool fuse_rf = rf_plan != 0;
   // The wide levels (1, 2) hold 94 % of the coefficients; the coarse levels are chains of small launches that
   // leave most of the chip idle.  With the fused forward kernel the wide levels' data is complete early, so
   // their histograms (and, below, their row filters) run on the part's helper stream BESIDE the coarse
@@ -672,7 +694,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
       dsx::RowFinalArgs rf;
       rf.r = row1;
       rf.f = f;
-      DSX_HIP(launch_rowfinal(rf, nb, s));
+      DSX_HIP(launch_rowfinal(rf_plan, rf, nb, s));
     } else if (fused && inv_wpb == 8) {
       const dim3 g8((f.nstrips * f.nseg + 7) / 8, nb);
       if (in_dtype == DSX_U16) hipLaunchKernelGGL((dsx::k_inv_march<0, true, 8>), g8, dim3(512), 0, s, f);
@@ -857,6 +879,7 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
 #endif
   if (const char* gm = getenv("DSX_GRAPH")) c->graph_mode = atoi(gm) != 0 ? 1 : 0;
   if (const char* nf = getenv("DSX_NO_FUSE_RF")) c->no_fuse_rf = atoi(nf) != 0;
+  if (const char* fw = getenv("DSX_FUSE_RF_WIDE")) c->fuse_rf_wide = atoi(fw) != 0;
   if (const char* ns = getenv("DSX_STREAMS")) c->n_streams = std::max(1, std::min(atoi(ns), (int)dsx_ctx::kMaxStreams));
   // DSX_PRIO=p0,p1,...: stream priority per sub-cohort stream (experiment hook; default: all equal)
   int prio[dsx_ctx::kMaxStreams] = {};

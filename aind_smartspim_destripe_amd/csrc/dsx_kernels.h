@@ -2256,8 +2256,10 @@ __global__ __launch_bounds__(64 * WPB, (FUSE && IN_KIND == 0) ? DSX_INV_MINW : 1
 // inv_march_body<.., PAIR>.  The arithmetic of both phases is the unfused chain's, operation for operation: results
 // are bit-identical (tests/test_gpu_parity.py::test_fused_rowfinal_is_bit_identical_to_the_unfused_chain).
 //
-// Shapes: uint16 planes, W % 8 == 0, H even, <= kRfWaves strips (W <= 2048), direct level-1 plan 1026 = 19 * 9 * 6
-// (2048-wide planes).  Everything else takes k_rowfilter + k_inv_march.
+// Shapes: uint16 planes, W % 8 == 0, H even, <= kRfWaves strips (W <= 2048), and a level-1 row-filter plan with a
+// compile-time instantiation: 1026 = 19 * 9 * 6 direct (2048-wide planes; two blocks per CU), 1002 values embedded in
+// 2048 (2000-wide: the production tile) and 902 in 1815 (1800-wide) -- one block of 8 waves per CU for those two,
+// against ONE block of 4 waves for their k_rowfilter.  Everything else takes k_rowfilter + k_inv_march.
 // ================================================================================================
 constexpr int kRfWaves = 8;
 constexpr int kRfRows = 2 * kRfWaves - 2;  // coefficient rows p per block
@@ -2455,7 +2457,7 @@ __device__ __forceinline__ void rowfinal_synth(const FinalArgs& a, const float2*
 
 // PLAN_ / CPL / GF_ / NT_ / HALO_ as in k_rowfilter; the block's row pairs are [kRfWaves - 1) * blockIdx.x + wave
 template <int CPL, int GF_, int NT_, int HALO_, int PLAN_>
-__global__ __launch_bounds__(64 * kRfWaves, 4) void k_rowfinal(RowFinalArgs a) {
+__global__ __launch_bounds__(64 * kRfWaves, CPL <= 18 ? 4 : 2) void k_rowfinal(RowFinalArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

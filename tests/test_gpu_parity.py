@@ -668,13 +668,13 @@ def test_graph_replay_is_bit_identical_to_eager_launches(monkeypatch):
 
 
 def test_fused_rowfinal_is_bit_identical_to_the_unfused_chain(monkeypatch):
-    """2048-wide uint16 planes run the level-1 row filter INSIDE the final kernel (k_rowfinal: Delta_1 stays in LDS, every
-    lane synthesises its own c_1 columns from level 2).  Same arithmetic, operation for operation: the result must equal
+    """2048-, 2000- and 1800-wide uint16 planes run the level-1 row filter INSIDE the final kernel (k_rowfinal: Delta_1
+    stays in LDS, every lane synthesises its own c_1 columns from level 2).  Same arithmetic, operation for operation: the result must equal
     the chain with k_rowfilter + k_inv_march (DSX_NO_FUSE_RF=1) bit for bit -- unsplit cohort (helper stream), a cohort
     split over the four streams, with and without the shading epilogue, a plane of constant rows, a plane with the
     cells config, and a short plane (2048 wide, 200 high: the last block is partial)."""
-    w = 2048
-    for h, n, shading in ((2048, 72, False), (2048, 20, True), (200, 40, False)):
+    for h, w, n, shading in ((2048, 2048, 72, False), (2048, 2048, 20, True), (200, 2048, 40, False),
+                             (1600, 2000, 40, False), (1600, 2000, 20, True), (1800, 1800, 40, False)):
         bank = synth.synthetic_bank(6, h, w)
         flatp = np.full((h, w), 300, np.uint16)
         rows = np.repeat((100 + 50 * np.arange(h, dtype=np.uint16) % 7)[:, None], w, axis=1).astype(np.uint16)
@@ -685,6 +685,7 @@ def test_fused_rowfinal_is_bit_identical_to_the_unfused_chain(monkeypatch):
             flat = (1.0 - 0.15 * (((yy - h / 2.0) / (h / 2.0)) ** 2 + ((xx - w / 2.0) / (w / 2.0)) ** 2)).astype(np.float32)
             dark = np.full((h, w), 100.0, np.float32)
         res = {}
+        monkeypatch.setenv("DSX_FUSE_RF_WIDE", "1")  # 2000- / 1800-wide planes: off by default (slower there)
         for mode in ("1", "0"):
             monkeypatch.setenv("DSX_NO_FUSE_RF", mode)
             e = eng_mod.DestripeEngine(0)
@@ -698,7 +699,7 @@ def test_fused_rowfinal_is_bit_identical_to_the_unfused_chain(monkeypatch):
                 e.close()
         assert res["0"][2].sum() > 0  # some planes took the cells config
         for a, b in zip(res["0"], res["1"]):
-            np.testing.assert_array_equal(np.asarray(a), np.asarray(b), err_msg=str((h, n, shading)))
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b), err_msg=str((h, w, n, shading)))
         if h == 2048 and not shading:  # and the reference: plane 1 of the stack against the oracle
             ref = orc.filter_stripes(stack[1], "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT)
             d = np.abs(res["0"][1][1].astype(np.int64) - ref.astype(np.uint16).astype(np.int64))
