@@ -427,8 +427,11 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.minmax = v.minmax;
     a.hist = v.hist;
     a.lvl = l; a.L = L;
-    static const int hist_rows = getenv("DSX_HIST_ROWS") ? atoi(getenv("DSX_HIST_ROWS")) : 32;
-    a.rows_per_block = std::max(1, std::min(hist_rows, 256));  // (16-bit per-lane counters: see k_hist)
+    // rows per block: each block zeroes and folds 32 KB of counters, so big cohorts take tall blocks (128 rows: + 1-2 %
+    // in the 4-stream run against 32), small ones keep enough blocks to spread over the chip (~512 per launch)
+    static const int hist_rows = getenv("DSX_HIST_ROWS") ? atoi(getenv("DSX_HIST_ROWS")) : 0;
+    const int auto_rows = std::max(32, std::min(128, (int)((long long)lp.h * nb / 512)));
+    a.rows_per_block = std::max(1, std::min(hist_rows > 0 ? hist_rows : auto_rows, 256));  // (16-bit per-lane counters: see k_hist)
     dim3 grid((lp.h + a.rows_per_block - 1) / a.rows_per_block, nb);
     LaunchScope ls(ctx, KC_HIST);
     hipLaunchKernelGGL(dsx::k_hist, grid, dim3(64 * dsx::kHistWaves), 0, hs, a);
@@ -1399,6 +1402,12 @@ int dsx_downsample2_u16(dsx_ctx* ctx, const void* d_src, void* d_dst, int Z, int
 
 int dsx_flatfield_correction(dsx_ctx* ctx, const void* d_img, int in_dtype, int H, int W, const float* d_flat,
                              const float* d_dark, int dark_h, int dark_w, float baseline, void* d_out) {
+  return dsx_flatfield_correction_rows(ctx, d_img, in_dtype, H, W, d_flat, d_dark, dark_h, dark_w, baseline, nullptr, d_out);
+}
+
+int dsx_flatfield_correction_rows(dsx_ctx* ctx, const void* d_img, int in_dtype, int H, int W, const float* d_flat,
+                                  const float* d_dark, int dark_h, int dark_w, float baseline,
+                                  const float* d_baseline_rows, void* d_out) {
   if (!ctx || !d_img || !d_flat || !d_dark || !d_out) return DSX_EINVAL;
   if (in_dtype != DSX_U16 && in_dtype != DSX_F32) return fail(ctx, DSX_EINVAL, "unknown element type");
   if (H <= 0 || W <= 0 || H > 65535) return fail(ctx, DSX_EINVAL, "flatfield_correction: bad plane shape");
@@ -1407,6 +1416,7 @@ int dsx_flatfield_correction(dsx_ctx* ctx, const void* d_img, int in_dtype, int 
   dsx::ShadeArgs a;
   a.src = d_img; a.flat = d_flat; a.dark = d_dark; a.dst = (uint16_t*)d_out;
   a.H = H; a.W = W; a.dark_w = dark_w; a.baseline = baseline;
+  a.baseline_rows = d_baseline_rows;
   DSX_HIP(hipSetDevice(ctx->device));
   const dim3 grid((W + 255) / 256, H);
   if (in_dtype == DSX_U16) hipLaunchKernelGGL(dsx::k_shade<true>, grid, dim3(256), 0, use_main(ctx), a);

@@ -114,6 +114,14 @@ struct InnerCodecs {
   size_t (*zstd_decompress)(void*, size_t, const void*, size_t) = nullptr;
   size_t (*zstd_bound)(size_t) = nullptr;
   unsigned (*zstd_is_error)(size_t) = nullptr;
+  // reusable contexts (optional symbols): ZSTD_compress / ZSTD_decompress build and tear down a context of ~1 MB per
+  // call -- per 256 KiB block here.  c-blosc keeps one per thread too.  Same streams, byte for byte.
+  void* (*zstd_create_cctx)() = nullptr;
+  size_t (*zstd_free_cctx)(void*) = nullptr;
+  size_t (*zstd_compress_cctx)(void*, void*, size_t, const void*, size_t, int) = nullptr;
+  void* (*zstd_create_dctx)() = nullptr;
+  size_t (*zstd_free_dctx)(void*) = nullptr;
+  size_t (*zstd_decompress_dctx)(void*, void*, size_t, const void*, size_t) = nullptr;
   // liblz4.so.1
   int (*lz4_decompress_safe)(const char*, char*, int, int) = nullptr;
 };
@@ -127,6 +135,12 @@ inline const InnerCodecs& inner_codecs() {
         c.zstd_decompress = (decltype(c.zstd_decompress))dlsym(h, "ZSTD_decompress");
         c.zstd_bound = (decltype(c.zstd_bound))dlsym(h, "ZSTD_compressBound");
         c.zstd_is_error = (decltype(c.zstd_is_error))dlsym(h, "ZSTD_isError");
+        c.zstd_create_cctx = (decltype(c.zstd_create_cctx))dlsym(h, "ZSTD_createCCtx");
+        c.zstd_free_cctx = (decltype(c.zstd_free_cctx))dlsym(h, "ZSTD_freeCCtx");
+        c.zstd_compress_cctx = (decltype(c.zstd_compress_cctx))dlsym(h, "ZSTD_compressCCtx");
+        c.zstd_create_dctx = (decltype(c.zstd_create_dctx))dlsym(h, "ZSTD_createDCtx");
+        c.zstd_free_dctx = (decltype(c.zstd_free_dctx))dlsym(h, "ZSTD_freeDCtx");
+        c.zstd_decompress_dctx = (decltype(c.zstd_decompress_dctx))dlsym(h, "ZSTD_decompressDCtx");
         break;
       }
     }
@@ -139,6 +153,35 @@ inline const InnerCodecs& inner_codecs() {
   });
   return c;
 }
+// One compression and one decompression context per thread, created on first use and released with the thread.
+struct ZstdThreadCtx {
+  void* c = nullptr;
+  void* d = nullptr;
+  ~ZstdThreadCtx() {
+    const InnerCodecs& lib = inner_codecs();
+    if (c && lib.zstd_free_cctx) lib.zstd_free_cctx(c);
+    if (d && lib.zstd_free_dctx) lib.zstd_free_dctx(d);
+  }
+};
+inline size_t zstd_compress_block(void* dst, size_t cap, const void* src, size_t n, int level) {
+  const InnerCodecs& lib = inner_codecs();
+  if (lib.zstd_create_cctx && lib.zstd_free_cctx && lib.zstd_compress_cctx) {
+    static thread_local ZstdThreadCtx t;
+    if (!t.c) t.c = lib.zstd_create_cctx();
+    if (t.c) return lib.zstd_compress_cctx(t.c, dst, cap, src, n, level);
+  }
+  return lib.zstd_compress(dst, cap, src, n, level);
+}
+inline size_t zstd_decompress_block(void* dst, size_t cap, const void* src, size_t n) {
+  const InnerCodecs& lib = inner_codecs();
+  if (lib.zstd_create_dctx && lib.zstd_free_dctx && lib.zstd_decompress_dctx) {
+    static thread_local ZstdThreadCtx t;
+    if (!t.d) t.d = lib.zstd_create_dctx();
+    if (t.d) return lib.zstd_decompress_dctx(t.d, dst, cap, src, n);
+  }
+  return lib.zstd_decompress(dst, cap, src, n);
+}
+
 inline bool zstd_available() {
   const InnerCodecs& c = inner_codecs();
   return c.zstd_compress && c.zstd_decompress && c.zstd_bound && c.zstd_is_error;
@@ -211,7 +254,7 @@ inline std::string blosc_decode(const unsigned char* src, size_t n, void* dst, s
       if (cs == neblock) {
         memcpy(out, src + pos, neblock);
       } else if (inner == kInnerZstd) {
-        const size_t r = lib.zstd_decompress(out, neblock, src + pos, cs);
+        const size_t r = zstd_decompress_block(out, neblock, src + pos, cs);
         if (lib.zstd_is_error(r) || r != neblock) return "blosc: bad zstd stream";
       } else if (inner == kInnerLz4) {
         if (lib.lz4_decompress_safe((const char*)src + pos, (char*)out, (int)cs, (int)neblock) != (int)neblock)
@@ -263,7 +306,7 @@ inline std::string blosc_encode(const void* src_, size_t n, int typesize, int cl
     const size_t bsize = (b + 1 == nblocks) ? n - b * blocksize : blocksize;
     const unsigned char* blk = src + b * blocksize;
     if (do_shuffle) { blosc_shuffle((size_t)typesize, bsize, blk, tmp.data()); blk = tmp.data(); }
-    size_t cs = lib.zstd_compress(comp.data(), bound, blk, bsize, zlevel);
+    size_t cs = zstd_compress_block(comp.data(), bound, blk, bsize, zlevel);
     const bool raw = lib.zstd_is_error(cs) || cs >= bsize;  // a stream as long as the block means "stored" to a reader
     if (raw) cs = bsize;
     const size_t at = out.size();

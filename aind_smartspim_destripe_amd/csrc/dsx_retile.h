@@ -128,6 +128,7 @@ struct ShadeArgs {
   uint16_t* dst;
   int H, W, dark_w;
   float baseline;
+  const float* baseline_rows;  // nullable: one value per plane row (a 2-D plane broadcasts baseline[:, None], :393-398)
 };
 
 template <bool U16>
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
   const float d = a.dark[(size_t)y * a.dark_w + x];
   float t = v > d ? v - d : 0.f;
   if (U16) t = truncf(t);
-  float c = t / a.flat[i] - a.baseline;
+  float c = t / a.flat[i] - (a.baseline_rows ? a.baseline_rows[y] : a.baseline);
   c = fminf(fmaxf(c, 0.f), 65535.f);
   a.dst[i] = (uint16_t)c;
 }

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "dsx_timer_start", "dsx_timer_stop", "dsx_profile_enable", "dsx_profile_read",
     "dsx_get_stats", "dsx_get_thresholds", "dsx_get_level", "dsx_set_stop_after",
     "dsx_bricks_to_planes_u16", "dsx_planes_to_bricks_u16", "dsx_downsample2_u16",
-    "dsx_flatfield_correction", "dsx_foreground_background",
+    "dsx_flatfield_correction", "dsx_flatfield_correction_rows", "dsx_foreground_background",
     "dsx_comm_unique_id", "dsx_comm_init", "dsx_comm_destroy", "dsx_comm_broadcast", "dsx_comm_allreduce_f64",
     "dsx_malloc_host", "dsx_free_host", "dsx_memcpy_h2d_async", "dsx_memcpy_d2h_async",
     "dsx_stream_wait", "dsx_stream_sync", "dsx_event_record", "dsx_event_sync",
@@ -130,6 +130,7 @@ def load_library(path=None):
     lib.dsx_foreground_background.argtypes = [vp, vp, i32, ctypes.c_size_t, ctypes.c_float,
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), vp]  # fmt: skip
     lib.dsx_flatfield_correction.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, ctypes.c_float, vp]
+    lib.dsx_flatfield_correction_rows.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, ctypes.c_float, vp, vp]
     lib.dsx_comm_unique_id.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
     lib.dsx_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, i32, i32]
     lib.dsx_comm_destroy.argtypes = [vp]
@@ -525,19 +526,31 @@ class DestripeEngine:
                 d_mask.free()
 
     def flatfield_correction(self, plane, flatfield, darkfield, baseline=0.0):
-        """One host plane (uint16 / float32) through ``dsx_flatfield_correction``; uint16 result."""
+        """One host plane (uint16 / float32) through ``dsx_flatfield_correction[_rows]``; uint16 result.
+        ``baseline``: a scalar, or one value per plane row."""
         a = np.ascontiguousarray(plane)
         flat = np.ascontiguousarray(flatfield, dtype=np.float32)
         dark = np.ascontiguousarray(darkfield, dtype=np.float32)
         H, W = a.shape
+        rows = None
+        if np.ndim(baseline) > 0:
+            rows = np.ascontiguousarray(baseline, dtype=np.float32).ravel()
+            if rows.size != H:
+                raise ValueError("a per-row baseline needs one value per plane row ({} != {})".format(rows.size, H))
+            baseline = 0.0
         bufs = [self.alloc(max(x.nbytes, 16)) for x in (a, flat, dark)] + [self.alloc(max(H * W * 2, 16))]
+        if rows is not None:
+            bufs.append(self.alloc(max(rows.nbytes, 16)))
         try:
             for b, x in zip(bufs, (a, flat, dark)):
                 b.upload(x)
-            rc = self._lib.dsx_flatfield_correction(self._ctx, ctypes.c_void_p(bufs[0].ptr), _dtype_code(a.dtype), H, W,
-                                                    ctypes.c_void_p(bufs[1].ptr), ctypes.c_void_p(bufs[2].ptr),
-                                                    dark.shape[0], dark.shape[1], float(baseline),
-                                                    ctypes.c_void_p(bufs[3].ptr))  # fmt: skip
+            if rows is not None:
+                bufs[4].upload(rows)
+            rc = self._lib.dsx_flatfield_correction_rows(self._ctx, ctypes.c_void_p(bufs[0].ptr), _dtype_code(a.dtype), H, W,
+                                                         ctypes.c_void_p(bufs[1].ptr), ctypes.c_void_p(bufs[2].ptr),
+                                                         dark.shape[0], dark.shape[1], float(baseline),
+                                                         ctypes.c_void_p(bufs[4].ptr) if rows is not None else None,
+                                                         ctypes.c_void_p(bufs[3].ptr))  # fmt: skip
             if rc == -1:
                 raise ValueError(self._lib.dsx_last_error(self._ctx).decode())
             self._check(rc)

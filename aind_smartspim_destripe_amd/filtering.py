@@ -156,16 +156,21 @@ def flatfield_correction(image_tiles, flatfield, darkfield, baseline=None, devic
     plane_shape = image_tiles.shape[-2:]
     if image_tiles.ndim < 2 or int(np.prod(image_tiles.shape[:-2])) != 1:
         raise ValueError("flatfield_correction takes one plane ([H, W] or [1, H, W])")
-    # a 2-D plane broadcasts baseline[:, None] over its rows (:393-398); a constant is all the kernel takes
-    if baseline.size and not np.all(baseline == baseline[0]):
-        raise NotImplementedError("per-row baselines are not implemented (the reference only uses zeros)")
+    # baseline[baseline_indxs] (:393-398, 409): index 0 of the array gets one value each -- the rows of a 2-D plane
+    # (k_shade takes one value per row), the single plane of a [1, H, W] stack (a scalar)
+    if baseline.size not in (1, image_tiles.shape[0]):
+        raise ValueError(
+            "operands could not be broadcast together with shapes {} {}".format(
+                image_tiles.shape, (baseline.size,) + (1,) * (image_tiles.ndim - 1)))
+    per_row = image_tiles.ndim == 2 and baseline.size == plane_shape[0] and baseline.size > 1
     eng = next((e[0] for k, e in _ENGINES.items() if k[0] == device), None)
     own = eng is None
     if own:
         eng = _engine.DestripeEngine(device)
     try:
         out = eng.flatfield_correction(_as_plane_dtype(image_tiles.reshape(plane_shape)), flatfield.reshape(plane_shape),
-                                       darkfield.reshape(plane_shape), float(baseline[0]) if baseline.size else 0.0)
+                                       darkfield.reshape(plane_shape),
+                                       baseline if per_row else (float(baseline[0]) if baseline.size else 0.0))
     finally:
         if own:
             eng.close()

@@ -428,7 +428,7 @@ def destripe_zarr(
     compressor="blosc",
     logger=None,
     device_retile=None,
-    io_threads=8,
+    io_threads=None,
     tile_name=None,
     group=None,
 ):
@@ -452,11 +452,22 @@ def destripe_zarr(
     left-over with the same geometry and codec is indistinguishable and harmless: rank 0 rewrites the same
     metadata, every rank rewrites its own chunks).  ``device=None`` takes the local rank (``LOCAL_RANK``), not the global one.
 
+    ``io_threads``: native threads that read / decompress and compress / write chunks (default: the cores this
+    process may run on).
+
     ``device_retile``: ``True`` = chunks are re-tiled into planes and back on the GPU (row f1; needs a
     uint16 store and chunk-aligned z blocks), ``False`` = host gather / scatter through
     :func:`execute_worker`, ``None`` = the device path whenever it applies.
     """
     logger = logger or logging.getLogger("dsx.zarr")
+    if io_threads is None:
+        # the chunk codecs are the bottleneck of this path (zstd level 5 runs at ~0.7 GB/s per core, the filter at
+        # > 500 GB/s): every core this process may use, as the reference's CO_CPUS consumers (zarr_destriper.py:1138)
+        try:
+            io_threads = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            io_threads = os.cpu_count() or 8
+        io_threads = max(1, min(int(io_threads), 64))
     src = MiniZarrArray.open(dataset_path)
     zyx = src.shape[-3:]
     if prediction_chunksize[1] < zyx[1] or prediction_chunksize[2] < zyx[2]:

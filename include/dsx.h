@@ -213,6 +213,12 @@ int dsx_png_unfilter(void* rows, int height, int stride, int bytes_per_pixel);
 int dsx_flatfield_correction(dsx_ctx* ctx, const void* d_img, int in_dtype, int H, int W,
                              const float* d_flat, const float* d_dark, int dark_h, int dark_w,
                              float baseline, void* d_out);
+/* The same with one baseline value per plane ROW (d_baseline_rows: H floats on the device, NULL = the scalar): what
+ * the reference's broadcast baseline[:, np.newaxis] does for a 2-D plane and a baseline of length H
+ * (filtering.py:393-398, 409).                                                                              */
+int dsx_flatfield_correction_rows(dsx_ctx* ctx, const void* d_img, int in_dtype, int H, int W,
+                                  const float* d_flat, const float* d_dark, int dark_h, int dark_w,
+                                  float baseline, const float* d_baseline_rows, void* d_out);
 
 /* get_foreground_background_mean() as a stand-alone call (filtering.py:54-88): a pixel is foreground
  * when float16(pixel) >= cutoff (the host derives cutoff from threshold_mask, 383.25 for the default

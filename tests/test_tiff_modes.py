@@ -354,6 +354,32 @@ def test_find_all_images_and_batch_filter_patched(tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_flatfield_correction_per_row_baseline():
+    """``baseline[:, np.newaxis]`` (filtering.py:393-398, 409): a 2-D plane takes one baseline value per ROW, a
+    [1, H, W] stack one per plane; a baseline of another length fails to broadcast (ValueError, as NumPy's)."""
+    from aind_smartspim_destripe_amd import filtering
+    from oracle import destripe_oracle as orc
+
+    rs = np.random.RandomState(5)
+    for dtype in (np.uint16, np.float32):
+        img = rs.randint(0, 4000, (37, 52)).astype(dtype)
+        flat = (0.7 + 0.6 * rs.rand(37, 52)).astype(np.float32)
+        dark = (90 + 20 * rs.rand(40, 60)).astype(np.float32)  # larger than the plane: cropped (:377)
+        base = (50.0 * rs.rand(37)).astype(np.float64)
+        out = filtering.flatfield_correction(img.copy(), flat, dark, base)
+        ref = orc.flatfield_correction(img.copy(), flat, dark, base)
+        assert out.dtype == np.uint16 and out.shape == ref.shape
+        d = np.abs(out.astype(np.int64) - ref.astype(np.int64))
+        assert d.max() <= 1 and (d > 0).mean() < 5e-3, (dtype, int(d.max()))
+        assert np.abs(ref.astype(np.int64) - orc.flatfield_correction(img.copy(), flat, dark).astype(np.int64)).max() > 10
+        one = filtering.flatfield_correction(img[None].copy(), flat[None], dark[:37, :52][None], np.array([7.0]))
+        ref1 = orc.flatfield_correction(img[None].copy(), flat[None], dark[:37, :52][None], np.array([7.0]))
+        assert np.abs(one.astype(np.int64) - ref1.astype(np.int64)).max() <= 1
+        with pytest.raises(ValueError):
+            filtering.flatfield_correction(img.copy(), flat, dark, np.zeros(5))
+
+
+@pytest.mark.gpu
 def test_gpu_flatfield_correction_golden(golden_misc):
     from aind_smartspim_destripe_amd import filtering
 
