@@ -151,6 +151,7 @@ struct CohortView {
   hipStream_t stream;
   hipStream_t helper;   // nullptr: everything on `stream`
   hipEvent_t* ev;       // 4 events of this part (helper fork / join, twice)
+  bool alone;           // the cohort runs as ONE part: its big kernels have the chip to themselves (march_segments)
   float* ws;
   dsx::PlaneStats* stats;
   unsigned* minmax;
@@ -347,11 +348,39 @@ hipError_t launch_rowfinal(int plan, const dsx::RowFinalArgs& a, int nb, hipStre
 
 // Row segmentation of the marching kernels: enough waves to fill the chip for small cohorts,
 // one segment per strip for large ones (each extra segment re-reads a 4-row halo).
-void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg) {
+// wpb > 0 (the fused level-1 kernels, wpb waves per block, 16 waves per CU): the segment count is also chosen against
+// the QUANTISATION of the launch -- blocks run in rounds of (CUs x 16 / wpb); 576 equal blocks on 512 slots take two
+// rounds, 512 take one.  Among the counts around the target the one with the smallest rounds x (rows per segment +
+// halo_rows) wins (halo_rows: the rows a segment recomputes, in the units of `rows`).
+void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg, int wpb = 0, int halo_rows = 0) {
   static const int target_waves = getenv("DSX_MARCH_WAVES") ? atoi(getenv("DSX_MARCH_WAVES")) : 256 * 16;
+  static const bool no_quant = getenv("DSX_NO_QUANT") && atoi(getenv("DSX_NO_QUANT")) != 0;
   int want = (target_waves + nb * nstrips - 1) / (nb * nstrips);
   const int max_seg = std::max(1, rows / 24);
   want = std::max(1, std::min(want, max_seg));
+  if (wpb > 0 && !no_quant) {
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+      if (cus <= 0) cus = 256;
+    }
+    const long long slots = (long long)cus * (16 / wpb);
+    double best = 1e300;
+    int best_n = want;
+    for (int n = std::max(1, want / 2); n <= std::min(max_seg, 2 * want + 1); ++n) {
+      const int rps = (rows + n - 1) / n;
+      const int ns = (rows + rps - 1) / rps;
+      const long long blocks = (long long)nb * ((nstrips * ns + wpb - 1) / wpb);
+      const long long rounds = (blocks + slots - 1) / slots;
+      // a launch that leaves most of the chip empty is no bargain either: count at least half a round
+      const double fill = std::max(0.5, (double)blocks / (double)slots);
+      const double cost = std::max((double)rounds, fill) * (double)(rps + halo_rows);
+      if (cost < best * 0.999) { best = cost; best_n = n; }
+    }
+    want = best_n;
+  }
   int rps = (rows + want - 1) / want;
   rps = std::max(1, std::min(rps, 4096));  // uint32 partial sums of k_fwd1_march
   *rows_per_seg = rps;
@@ -492,7 +521,9 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
       f.aa2_off = l2.aa_off; f.da2_off = l2.da_off;
       f.h2 = l2.h; f.w2 = l2.w; f.ld2 = l2.ld; f.lda2 = l2.lda;
       f.nstrips = (l2.w + dsx::kFuseOut - 1) / dsx::kFuseOut;
-      march_segments(nb, f.nstrips, l2.h, &f.nseg, &f.rows_per_seg);
+      // (a cohort split over the streams shares the chip with the other parts' kernels: rounds mean nothing there --
+      //  measured 65.6 k with against 66.2 k planes/s without; alone: forward kernel 1.39 -> 1.14 ms per 256 planes)
+      march_segments(nb, f.nstrips, l2.h, &f.nseg, &f.rows_per_seg, v.alone ? 8 : 0, 2);
     }
     dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
     LaunchScope ls(ctx, l == 0 ? KC_FWD1 : KC_FWD);
@@ -730,6 +761,7 @@ CohortView make_view(dsx_ctx* ctx, int po, hipStream_t stream, int part = 0, boo
   static const int force_helper = getenv("DSX_HELPER") ? atoi(getenv("DSX_HELPER")) : -1;
   const bool use = force_helper >= 0 ? force_helper != 0 : helper;
   v.helper = (!use || ctx->profiling || ctx->stop_after != 0) ? nullptr : ctx->helper[part];
+  v.alone = helper;
   v.ev = ctx->ev_h[part];
   v.ws = ctx->d_ws + (size_t)po * ctx->plan.plane_floats;
   v.stats = ctx->d_stats + po;
