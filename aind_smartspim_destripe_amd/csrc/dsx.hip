@@ -91,6 +91,8 @@ struct dsx_ctx {
   // DSX_EVALUE instead and clears the word.
   unsigned* h_sticky = nullptr;
   unsigned* d_sticky = nullptr;
+  // dsx_set_stack_mode: the planes of a call share ONE Otsu threshold per level (the reference's 3-D input mode)
+  bool stack_mode = false;
   bool no_fuse_rf = false;  // DSX_NO_FUSE_RF=1: k_rowfilter + k_inv_march instead of k_rowfinal (same bits)
   bool fuse_rf_wide = false;  // DSX_FUSE_RF_WIDE=1: k_rowfinal for 2000- / 1800-wide planes too (slower there; rowfinal_plan)
   // DSX_ABLATE environment variable (timing-only switches that return WRONG pixels): read only by a library built
@@ -456,6 +458,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.minmax = v.minmax;
     a.hist = v.hist;
     a.lvl = l; a.L = L;
+    a.shared = ctx->stack_mode ? 1 : 0;
     // rows per block: each block zeroes and folds 32 KB of counters, so big cohorts take tall blocks (128 rows: + 1-2 %
     // in the 4-stream run against 32), small ones keep enough blocks to spread over the chip (~512 per launch)
     static const int hist_rows = getenv("DSX_HIST_ROWS") ? atoi(getenv("DSX_HIST_ROWS")) : 0;
@@ -487,6 +490,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
       g.stats = v.stats;
       g.fg_cutoff = ctx->fg_cutoff;
       g.F = ctx->wl_len;
+      g.shared = ctx->stack_mode ? 1 : 0;
       memcpy(g.lo, ctx->wl[0], sizeof(float) * ctx->wl_len);
       memcpy(g.hi, ctx->wl[1], sizeof(float) * ctx->wl_len);
       const dim3 gg((lp.w + dsx::kGenTW - 1) / dsx::kGenTW, (lp.h + dsx::kGenTH - 1) / dsx::kGenTH, nb);
@@ -513,6 +517,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     f.stats = v.stats;
     f.fg_cutoff = ctx->fg_cutoff;
     f.ablate = ctx->ablate;
+    f.shared = ctx->stack_mode ? 1 : 0;
     f.fg_cutoff_u16 = (unsigned)std::min(65536.0, std::max(0.0, ceil((double)ctx->fg_cutoff)));
     f.nstrips = (lp.w + dsx::kMarchOut - 1) / dsx::kMarchOut;
     march_segments(nb, f.nstrips, lp.h, &f.nseg, &f.rows_per_seg);
@@ -574,6 +579,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     a.max_thr[1] = (float)ctx->cfg[1].max_threshold;
     a.L = L;
     a.sticky = ctx->d_sticky;
+    a.shared = ctx->stack_mode ? 1 : 0;
     LaunchScope ls(ctx, KC_OTSU);
     hipLaunchKernelGGL(dsx::k_otsu, dim3(L, nb), dim3(64), 0, s, a);
     DSX_HIP(hipGetLastError());
@@ -786,7 +792,7 @@ CohortView make_view(dsx_ctx* ctx, int po, hipStream_t stream, int part = 0, boo
 int run_cohort_split(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void* d_out, int out_dtype,
                      int32_t* d_cfg_used, size_t in_plane, size_t out_plane) {
   int parts = ctx->n_streams;
-  if (ctx->profiling || ctx->stop_after != 0) parts = 1;
+  if (ctx->profiling || ctx->stop_after != 0 || ctx->stack_mode) parts = 1;  // stack mode: one control block, one chain
   while (parts > 1 && nb / parts < 16) --parts;  // keep every part big enough to fill the chip
   if (parts <= 1) {
     hipStream_t main = use_main(ctx);  // joins whatever split cohort is still running
@@ -1149,6 +1155,8 @@ int dsx_run_device(dsx_ctx* ctx, const void* d_in, int in_dtype, int n, void* d_
   if ((in_dtype != DSX_U16 && in_dtype != DSX_F32) || (out_dtype != DSX_U16 && out_dtype != DSX_F32))
     return fail(ctx, DSX_EINVAL, "unknown element type");
   DSX_HIP(hipSetDevice(ctx->device));
+  if (ctx->stack_mode && n > ctx->max_batch)
+    return fail(ctx, DSX_ELIMIT, "stack mode: all planes of the stack must fit one cohort (plan with max_batch >= n)");
   const dsx::Plan& p = ctx->plan;
   const size_t in_plane = (size_t)p.H * p.W * elem_size(in_dtype);
   const size_t out_plane = (size_t)p.Hout * p.Wout * elem_size(out_dtype);
@@ -1182,6 +1190,8 @@ int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, i
   const size_t in_plane = (size_t)p.H * p.W * elem_size(in_dtype);
   const size_t out_plane = (size_t)p.Hout * p.Wout * elem_size(out_dtype);
   const int B = ctx->max_batch;
+  if (ctx->stack_mode && n > B)
+    return fail(ctx, DSX_ELIMIT, "stack mode: all planes of the stack must fit one cohort (plan with max_batch >= n)");
   const size_t need_in = in_plane * B, need_out = out_plane * B + sizeof(int32_t) * B;
   if (ctx->stage_in_bytes < need_in) {
     if (ctx->d_stage_in) (void)hipFree(ctx->d_stage_in);
@@ -1651,6 +1661,11 @@ int dsx_png_unfilter(void* rows, int height, int stride, int bytes_per_pixel) {
 }
 
 /* ---- debug hooks ---------------------------------------------------------------------------- */
+int dsx_set_stack_mode(dsx_ctx* ctx, int on) {
+  if (!ctx) return DSX_EINVAL;
+  ctx->stack_mode = on != 0;
+  return DSX_OK;
+}
 int dsx_set_stop_after(dsx_ctx* ctx, int stage) {
   if (!ctx || stage < 0 || stage > 2) return DSX_EINVAL;
   ctx->stop_after = stage;

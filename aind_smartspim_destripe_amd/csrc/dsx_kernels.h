@@ -194,6 +194,9 @@ struct Fwd1Args {
   long long aa2_off, da2_off;
   int h2, w2, ld2, lda2;
   int ablate;  // diagnosis only (DSX_ABLATE): 16 = the fused forward kernel stores nothing (timing of its store path)
+  // stack mode (the reference's 3-D input, filtering.py:188): ONE Otsu threshold per level for all planes of the call --
+  // every plane's min / max and histogram go to plane 0's slots (k_hist, k_otsu read them there too)
+  int shared;
 };
 
 constexpr int kMarchCols = 256;                 // input columns per wave
@@ -775,7 +778,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   qmin = wave_min_f32(qmin);
   qmax = wave_max_f32(qmax);
   if (lane == 0 && qmin <= qmax) {
-    unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
+    unsigned* mm = a.minmax + ((long long)(a.shared ? 0 : plane) * a.L + a.lvl) * 2;
     atomicMax(&mm[0], ~as_u32(qmin));
     atomicMax(&mm[1], as_u32(qmax));
   }
@@ -783,7 +786,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     q2min = wave_min_f32(q2min);
     q2max = wave_max_f32(q2max);
     if (lane == 0 && q2min <= q2max) {
-      unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl + 1) * 2;
+      unsigned* mm = a.minmax + ((long long)(a.shared ? 0 : plane) * a.L + a.lvl + 1) * 2;
       atomicMax(&mm[0], ~as_u32(q2min));
       atomicMax(&mm[1], as_u32(q2max));
     }
@@ -867,6 +870,7 @@ struct HistArgs {
   unsigned* hist;  // [B][L][256]
   int lvl, L;
   int rows_per_block;
+  int shared;  // stack mode: plane 0's min / max and histogram slots for every plane (Fwd1Args::shared)
 };
 
 // Bin of q = largest i with edges[i] <= q (numpy's estimate-then-correct rule ends there too).
@@ -905,7 +909,8 @@ __global__ __launch_bounds__(64 * kHistWaves) void k_hist(HistArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int plane = blockIdx.y;
-  const unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
+  const int splane = a.shared ? 0 : plane;
+  const unsigned* mm = a.minmax + ((long long)splane * a.L + a.lvl) * 2;
   const float qmin = as_f32(~mm[0]), qmax = as_f32(mm[1]);
   if (!(qmin < qmax)) return;  // constant cH^2: Otsu early-out, no histogram (block-uniform)
   const HistBins hb(qmin, qmax);
@@ -968,7 +973,7 @@ __global__ __launch_bounds__(64 * kHistWaves) void k_hist(HistArgs a) {
       const unsigned v = s_cnt[tid * 32 + ((j + tid) & 31)];
       n += (v & 0xFFFFu) + (v >> 16);
     }
-    if (n) atomicAdd(&a.hist[((long long)plane * a.L + a.lvl) * 256 + tid], n);
+    if (n) atomicAdd(&a.hist[((long long)splane * a.L + a.lvl) * 256 + tid], n);
   }
 }
 
@@ -988,6 +993,7 @@ struct OtsuArgs {
   float max_thr[2];
   int L;
   unsigned* sticky;  // host-mapped flag word of the context (dsx_ctx::h_sticky), may be null
+  int shared;        // stack mode: every plane takes its thresholds from plane 0's min / max and histogram slots
 };
 
 // Otsu value of one plane and level from its 256-bin histogram, by ONE wave (64 lanes): returns the value on every
@@ -1084,10 +1090,11 @@ __global__ __launch_bounds__(64) void k_otsu(OtsuArgs a) {
     a.means[2 * plane + 1] = back;
   }
   const long long pl = (long long)plane * a.L + lvl;
-  const unsigned* mm = a.minmax + pl * 2;
+  const long long spl = (long long)(a.shared ? 0 : plane) * a.L + lvl;
+  const unsigned* mm = a.minmax + spl * 2;
   const float q_lo = as_f32(~mm[0]), q_hi = as_f32(mm[1]);
   __shared__ double s_scratch[6 * 256];
-  const double otsu = otsu_from_hist(q_lo, q_hi, a.hist + pl * 256, s_scratch, lane);
+  const double otsu = otsu_from_hist(q_lo, q_hi, a.hist + spl * 256, s_scratch, lane);
   if (lane == 0) {
     const double t = fmin(otsu >= 0 ? sqrt(otsu) : 0.0, (double)a.max_thr[cfg]);
     a.otsu[pl] = (float)otsu;

@@ -41,6 +41,7 @@ struct GenFwdArgs {
   PlaneStats* stats;
   float fg_cutoff;
   int F;
+  int shared;  // stack mode: plane 0's min / max slots for every plane (Fwd1Args::shared)
   float lo[kMaxTaps], hi[kMaxTaps];  // dec_lo, dec_hi
 };
 
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void k_fwd_gen(GenFwdArgs a) {
   qmin = wave_min_f32(qmin);
   qmax = wave_max_f32(qmax);
   if ((tid & 63) == 0 && qmin <= qmax) {
-    unsigned* mm = a.minmax + ((long long)plane * a.L + a.lvl) * 2;
+    unsigned* mm = a.minmax + ((long long)(a.shared ? 0 : plane) * a.L + a.lvl) * 2;
     atomicMax(&mm[0], ~as_u32(qmin));
     atomicMax(&mm[1], as_u32(qmax));
   }

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "dsx_set_shading_device", "dsx_constants_device", "dsx_run_host", "dsx_run_device", "dsx_sync",
     "dsx_malloc", "dsx_free", "dsx_memcpy_h2d", "dsx_memcpy_d2h", "dsx_memcpy_d2d",
     "dsx_timer_start", "dsx_timer_stop", "dsx_profile_enable", "dsx_profile_read",
-    "dsx_get_stats", "dsx_get_thresholds", "dsx_get_level", "dsx_set_stop_after",
+    "dsx_get_stats", "dsx_get_thresholds", "dsx_get_level", "dsx_set_stop_after", "dsx_set_stack_mode",
     "dsx_bricks_to_planes_u16", "dsx_planes_to_bricks_u16", "dsx_downsample2_u16",
     "dsx_flatfield_correction", "dsx_flatfield_correction_rows", "dsx_foreground_background",
     "dsx_comm_unique_id", "dsx_comm_init", "dsx_comm_destroy", "dsx_comm_broadcast", "dsx_comm_allreduce_f64",
@@ -122,6 +122,7 @@ def load_library(path=None):
     lib.dsx_get_thresholds.argtypes = [vp, i32, i32, f32p, f32p]
     lib.dsx_get_level.argtypes = [vp, i32, i32, i32, vp]
     lib.dsx_set_stop_after.argtypes = [vp, i32]
+    lib.dsx_set_stack_mode.argtypes = [vp, i32]
     lib.dsx_graph_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     lib.dsx_set_wavelet.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 4 + [i32]
     lib.dsx_bricks_to_planes_u16.argtypes = [vp, vp, vp] + [i32] * 7
@@ -560,6 +561,10 @@ class DestripeEngine:
                 b.free()
 
     # -- parity hooks ----------------------------------------------------------------------------
+    def set_stack_mode(self, on):
+        """Planes of one ``run`` call share one Otsu threshold per level (the reference's 3-D input mode)."""
+        self._check(self._lib.dsx_set_stack_mode(self._ctx, 1 if on else 0))
+
     def set_stop_after(self, stage):
         self._check(self._lib.dsx_set_stop_after(self._ctx, int(stage)))
 

@@ -266,17 +266,31 @@ def log_space_fft_filtering(
 
     Returns float64 ``[H + H % 2, W + W % 2]`` like the reference (computed in float32 on the
     device; within 1e-4 relative of the NumPy/SciPy path).
+
+    A 3-D ``[n, H, W]`` input is the reference's stack mode (``:182-183, 188, 210-211``): every plane is decomposed
+    on its own, but each level takes ONE Otsu threshold from the coefficients of all planes (``dsx_set_stack_mode``).
+    Planes that are to be filtered independently go through :func:`destripe_planes`.
     """
     image = np.asarray(input_image)
-    if image.ndim != 2:
-        raise ValueError(
-            "only 2-D planes are supported (the reference's 3-D mode uses one Otsu threshold for the "
-            "whole stack and is not what the chunk map calls; use destripe_planes for batches)"
-        )
+    if image.ndim not in (2, 3):
+        raise ValueError("log_space_fft_filtering takes a 2-D plane or a 3-D stack [n, H, W]")
     cfg = {"wavelet": wavelet, "level": level, "sigma": sigma, "max_threshold": max_threshold}
     if sigma <= 0:
         raise ValueError("sigma must be positive")
-    _warn_levels(image.shape, cfg)
+    _warn_levels(image.shape[-2:], cfg)
+    if image.ndim == 3:
+        if image.shape[0] == 0:
+            raise ValueError("empty stack")
+        planes = image if image.dtype in (np.uint16, np.float32) else np.stack([_as_plane_dtype(p) for p in image])
+        if planes.dtype not in (np.uint16, np.float32):
+            planes = planes.astype(np.float32)
+        eng = get_engine(image.shape[-2:], cfg, cfg, microscope_high_int=2700, max_batch=int(image.shape[0]))
+        eng.set_stack_mode(True)
+        try:
+            out = eng.run(np.ascontiguousarray(planes), out_dtype=np.float32)
+        finally:
+            eng.set_stack_mode(False)
+        return out.astype(np.float64)
     eng = get_engine(image.shape, cfg, cfg, microscope_high_int=2700, max_batch=1)
     out = eng.run(_as_plane_dtype(image)[None], out_dtype=np.float32)[0]
     return out.astype(np.float64)

@@ -210,6 +210,12 @@ int dsx_png_unfilter(void* rows, int height, int stride, int bytes_per_pixel);
 /* flatfield_correction() of one plane as a stand-alone call (filtering.py:338-414): dark subtraction
  * (integer planes truncate, :400-403), division by the flat, baseline, clip, uint16.  dark is
  * [dark_h][dark_w] >= the plane and is cropped to it (:377).  Device pointers, asynchronous.   */
+/* Stack mode = the 3-D input mode of log_space_fft_filtering() (filtering.py:182-183, 188, 210-211): the planes of
+ * ONE dsx_run_* call are a stack that shares one Otsu threshold per decomposition level (min / max of cH^2 and the
+ * 256-bin histogram are taken over all planes; row medians and the FFT stay per plane row).  The whole stack must
+ * fit one cohort (n <= max_batch of dsx_plan, else DSX_ELIMIT).  Off by default: planes are independent.       */
+int dsx_set_stack_mode(dsx_ctx* ctx, int on);
+
 int dsx_flatfield_correction(dsx_ctx* ctx, const void* d_img, int in_dtype, int H, int W,
                              const float* d_flat, const float* d_dark, int dark_h, int dark_w,
                              float baseline, void* d_out);

@@ -395,8 +395,12 @@ def log_space_fft_filtering(
     """
     bank = as_bank(wavelet)
     input_image = np.asarray(input_image)
+    if input_image.ndim == 3:
+        if return_stages or mask_overrides is not None or otsu_overrides is not None:
+            raise ValueError("stages / overrides are for 2-D planes")
+        return _log_space_fft_filtering_stack(input_image, bank, level, sigma, max_threshold)
     if input_image.ndim != 2:
-        raise ValueError("the oracle restates the 2-D plane path only")
+        raise ValueError("the oracle restates the 2-D plane path and the 3-D stack mode only")
     input_image_log = np.log(1.0 + input_image)
     if input_image_log.dtype == np.float16:
         input_image_log = input_image_log.astype(np.float32)
@@ -416,6 +420,28 @@ def log_space_fft_filtering(
     if return_stages:
         return img_filtered, stages
     return img_filtered
+
+
+def _log_space_fft_filtering_stack(stack, bank, level, sigma, max_threshold):
+    """The 3-D input mode of ``filtering.py:139-224``: ``pywt.wavedec2`` transforms the last two axes of every plane,
+    ``width_fraction = sigma / min(shape[1:])`` (``:182-183``), and the per-level loop runs on the STACKED band -- one
+    Otsu threshold per level over all planes (``threshold_otsu(ch_sq)`` sees the 3-D array, ``:188``), row medians
+    and FFT along the last axis, ``s = fft.shape[1] * width_fraction`` (``:210-213``)."""
+    log = np.log(1.0 + stack)
+    if log.dtype == np.float16:
+        log = log.astype(np.float32)
+    per_plane = [wavedec2(p, level=level, bank=bank) for p in log]
+    nlev = len(per_plane[0]) - 1
+    width_fraction = sigma / min(stack.shape[1:])
+    filtered = [[c[0]] for c in per_plane]
+    for i in range(1, nlev + 1):
+        ch = np.stack([c[i][0] for c in per_plane])
+        s = ch.shape[1] * width_fraction
+        ch_f = filter_level(ch, s, max_threshold)
+        for k, c in enumerate(per_plane):
+            filtered[k].append((ch_f[k], c[i][1], c[i][2]))
+    out = np.stack([waverec2(f, bank) for f in filtered])
+    return np.exp(out) + 1.0
 
 
 def flatfield_correction(image_tiles, flatfield, darkfield, baseline=None):

@@ -115,6 +115,40 @@ def test_golden_small_planes(engine, golden_small):
         assert rel.max() < REL_TOL, (case, float(rel.max()))
 
 
+def test_stack_mode_3d_input_vs_golden():
+    """The reference's 3-D input mode (filtering.py:182-183, 188, 210-211): ONE Otsu threshold per level for the whole
+    stack.  16 runs of the real reference (tests/golden/stack3d.npz, oracle/make_golden_stack3d.py): two stacks (one
+    with odd planes), both configs, full depth and level 2, uint16 and float32 input.  A plane of the stack carries a
+    bright block, so its coefficients set the histogram range of every plane: filtering the planes independently gives
+    another result (checked), the stack mode must give the reference's."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stack3d.npz"), allow_pickle=False)
+    differs = 0
+    for case in [str(c) for c in g["cases"]]:
+        name, cfg_name, lvl, dt = case.split("__")
+        x = g[name + "__in"] if dt == "u16" else g[name + "__in"].astype(np.float32)
+        cfg = dict(CFGS[cfg_name])
+        cfg["level"] = None if lvl == "Lmax" else int(lvl[1:])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = filtering.log_space_fft_filtering(x, **cfg)
+            alone = np.stack([filtering.log_space_fft_filtering(p, **cfg) for p in x])
+        ref = g[case + "__out"]
+        assert out.shape == ref.shape and out.dtype == np.float64, case
+        rel = _rel(out, ref)
+        assert rel.max() < REL_TOL, (case, float(rel.max()))
+        differs += int(_rel(alone, ref).max() > 10 * REL_TOL)
+    assert differs >= 8  # the shared threshold matters on these stacks
+    # the stack must fit one cohort, and the mode is off again afterwards
+    e = eng_mod.DestripeEngine(0)
+    try:
+        e.plan(64, 96, synth.CELLS_CONFIG, synth.CELLS_CONFIG, 2700, max_batch=2)
+        e.set_stack_mode(True)
+        with pytest.raises(eng_mod.DsxError, match="stack mode"):
+            e.run(g["a__in"], out_dtype=np.float32)
+    finally:
+        e.close()
+
+
 def test_reference_unit_test_inputs(golden_small):
     """The inputs of the reference's own tests (code/tests/test_filtering.py:151-180)."""
     g = golden_small
@@ -145,7 +179,7 @@ def test_level0_and_errors():
     with pytest.raises(ValueError):
         filtering.log_space_fft_filtering(img, level=1, sigma=-3)
     with pytest.raises(ValueError):
-        filtering.log_space_fft_filtering(np.zeros((2, 8, 8), np.float32), level=1)
+        filtering.log_space_fft_filtering(np.zeros((2, 2, 8, 8), np.float32), level=1)
 
 
 @pytest.mark.parametrize("shape", [(1800, 1800), (1600, 2000), (2048, 2048)])

@@ -7,6 +7,7 @@ float32 regime (float32 input, the Zarr path): PyWavelets accumulates in float32
 order, so agreement is at float32 round-off (1e-5 relative on the output).
 """
 
+import os
 import warnings
 
 import numpy as np
@@ -284,3 +285,23 @@ def test_width_sweep_both_regimes(golden_sweep):
                 else:
                     moved += 1
     assert moved <= max(2, n // 50), (moved, n)
+
+
+def test_oracle_stack_mode_3d_against_the_reference():
+    """3-D input mode (one Otsu threshold per level for the stack): 16 runs of the real reference
+    (oracle/make_golden_stack3d.py).  float64 regime to 1e-11; float32 input follows the reference's float32 arithmetic
+    only to its own round-off (same Otsu bins: a different bin would show as percent-level differences)."""
+    from aind_smartspim_destripe_amd import synth
+    from oracle import destripe_oracle as orc
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stack3d.npz"), allow_pickle=False)
+    cfgs = {"cells": synth.CELLS_CONFIG, "nocells": synth.NO_CELLS_CONFIG}
+    for case in [str(c) for c in g["cases"]]:
+        name, cfg_name, lvl, dt = case.split("__")
+        x = g[name + "__in"] if dt == "u16" else g[name + "__in"].astype(np.float32)
+        cfg = cfgs[cfg_name]
+        out = orc.log_space_fft_filtering(x, cfg["wavelet"], None if lvl == "Lmax" else int(lvl[1:]), cfg["sigma"],
+                                          cfg["max_threshold"])
+        ref = g[case + "__out"]
+        rel = np.abs(out - ref) / np.abs(ref)
+        assert rel.max() < (1e-11 if dt == "u16" else 2e-5), (case, float(rel.max()))
