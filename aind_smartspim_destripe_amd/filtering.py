@@ -334,9 +334,13 @@ def filter_stripes(
         raise ValueError("filter_stripes takes one 2-D plane; use destripe_planes for a stack")
     flatfield, darkfield = _resolve_shading(shadow_correction, input_tile_path)
     _warn_levels(image.shape, cells_config, no_cells_config)
+    plane = _as_plane_dtype(image)[None]
+    if _engine._wavelet_key(cells_config) != _engine._wavelet_key(no_cells_config):
+        out = _destripe_planes_two_wavelets(plane, no_cells_config, cells_config, microscope_high_int, flatfield, darkfield,
+                                            np.uint16 if flatfield is not None else np.float32, 1, False, 0)[0]  # fmt: skip
+        return out if flatfield is not None else out.astype(np.float64)
     eng = get_engine(image.shape, cells_config, no_cells_config, microscope_high_int, flatfield, darkfield,
                      max_batch=1)  # fmt: skip
-    plane = _as_plane_dtype(image)[None]
     if flatfield is not None:
         return eng.run(plane, out_dtype=np.uint16)[0]
     return eng.run(plane, out_dtype=np.float32)[0].astype(np.float64)
@@ -365,8 +369,42 @@ def destripe_planes(
         raise ValueError("planes must be [n, H, W]")
     flatfield, darkfield = _resolve_shading(shadow_correction, input_tile_path)
     _warn_levels(planes.shape[1:], cells_config, no_cells_config)
-    eng = get_engine(planes.shape[1:], cells_config, no_cells_config, microscope_high_int, flatfield,
-                     darkfield, max_batch=max_batch, device=device)  # fmt: skip
     if planes.dtype != np.uint16 and planes.dtype != np.float32:
         planes = np.stack([_as_plane_dtype(p) for p in planes]) if len(planes) else planes.astype(np.float32)
+    if _engine._wavelet_key(cells_config) != _engine._wavelet_key(no_cells_config):
+        return _destripe_planes_two_wavelets(planes, no_cells_config, cells_config, microscope_high_int, flatfield,
+                                             darkfield, out_dtype, max_batch, return_config, device)  # fmt: skip
+    eng = get_engine(planes.shape[1:], cells_config, no_cells_config, microscope_high_int, flatfield,
+                     darkfield, max_batch=max_batch, device=device)  # fmt: skip
     return eng.run(planes, out_dtype=out_dtype, return_cfg=return_config)
+
+
+def _destripe_planes_two_wavelets(planes, no_cells_config, cells_config, microscope_high_int, flatfield, darkfield,
+                                  out_dtype, max_batch, return_config, device):
+    """The two configs name DIFFERENT wavelets.  One launch chain decomposes a plane before its config is known (the
+    fg/bg statistic is fused into the first kernel), so it cannot switch filter banks per plane; the reference decides
+    first and decomposes afterwards (``filtering.py:459-467``).  Same order here: the statistic of every plane
+    (``dsx_foreground_background``), the reference's decision rule, then one engine per config (both of its slots hold
+    that config) over the planes that chose it."""
+    n = planes.shape[0]
+    cutoff = _foreground_cutoff(0.3)
+    which = np.zeros(n, dtype=np.int32)
+    probe = get_engine(planes.shape[1:], no_cells_config, no_cells_config, microscope_high_int, flatfield, darkfield,
+                       max_batch=max_batch, device=device)  # fmt: skip
+    for k in range(n):
+        fore, back, _ = probe.foreground_background(planes[k], cutoff, want_mask=False)
+        which[k] = 1 if (fore > back and fore > microscope_high_int) else 0
+    out = None
+    for w, cfg in ((0, no_cells_config), (1, cells_config)):
+        idx = np.nonzero(which == w)[0]
+        if idx.size == 0:
+            continue
+        eng = get_engine(planes.shape[1:], cfg, cfg, microscope_high_int, flatfield, darkfield,
+                         max_batch=max_batch, device=device)  # fmt: skip
+        res = eng.run(np.ascontiguousarray(planes[idx]), out_dtype=out_dtype)
+        if out is None:
+            out = np.empty((n,) + res.shape[1:], dtype=res.dtype)
+        out[idx] = res
+    if out is None:
+        out = np.empty((0,) + tuple(s + (s & 1) for s in planes.shape[1:]), dtype=out_dtype)
+    return (out, which) if return_config else out

@@ -201,6 +201,20 @@ def test_gpu_wavelet_batch_configs_statistic_shading_and_casts():
             e.plan(h, w, dict(cells, wavelet="nope"), dict(nocells, wavelet="nope"), 2500, max_batch=1)
     finally:
         e.close()
+    # the two configs name DIFFERENT wavelets: the host layer decides per plane first (dsx_foreground_background), then
+    # runs every plane through an engine of the bank its config names -- the reference's order (filtering.py:459-467)
+    mixed_cells, mixed_nocells = dict(synth.CELLS_CONFIG, wavelet="sym4"), dict(synth.NO_CELLS_CONFIG, wavelet="db3")
+    got, used = filtering.destripe_planes(planes, "t", mixed_nocells, mixed_cells, None, 2500, out_dtype=np.float32,
+                                          return_config=True)
+    assert set(int(u) for u in used) == {0, 1}
+    for k in range(5):
+        which, _, _ = orc.select_config(planes[k], mixed_nocells, dict(mixed_cells, wavelet=bank), 2500)
+        assert int(used[k]) == which
+        ref = orc.filter_stripes(planes[k], "t", mixed_nocells, dict(mixed_cells, wavelet=bank), None, 2500)
+        rel = np.abs(got[k] - ref) / np.abs(ref)
+        assert (rel > 1e-4).mean() < 2e-3 and rel.max() < 0.5, (k, float(rel.max()))
+    one = filtering.filter_stripes(planes[0], "t", mixed_nocells, mixed_cells, None, 2500)
+    np.testing.assert_array_equal(one.astype(np.float32), got[0])
     # reference API with a wavelet name, float32 plane, even shape; shading epilogue vs the oracle's
     x = synth.synthetic_plane(3, 96, 128)
     rng = np.random.RandomState(5)
