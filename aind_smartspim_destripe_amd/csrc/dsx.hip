@@ -336,7 +336,11 @@ hipError_t launch_rowfinal_t(const dsx::RowFinalArgs& a, int nb, hipStream_t s) 
   }
   const size_t smem = (size_t)a.r.M * (dsx::kRfWaves + 1) * sizeof(float2);
   const int np = (a.f.hout + 1) / 2;
-  const dim3 grid((np + dsx::kRfRows - 1) / dsx::kRfRows, nb);
+  int nblk = (np + dsx::kRfRows - 1) / dsx::kRfRows;
+#if DSX_RF_XCD
+  nblk = (nblk + 7) / 8 * 8;  // the kernel deals runs of consecutive blocks to the 8 compute dies
+#endif
+  const dim3 grid(nblk, nb);
   hipLaunchKernelGGL(kern, grid, dim3(64 * dsx::kRfWaves), smem, s, a);
   return hipGetLastError();
 }

@@ -33,6 +33,12 @@
 #ifndef DSX_FWD_STEADY
 #define DSX_FWD_STEADY 1  // bit 0: steady-state row loop in interior strips, bit 1: in edge strips too (spills)
 #endif
+#ifndef DSX_RF_XCD
+// k_rowfinal: blocks that share rows on the same compute die.  Measured and left OFF: 1.6 MB per plane less HBM traffic
+// (25.0 -> 23.4), but 4 % SLOWER (61.9 k against 64.5 k planes/s, profiles/r3_fused_rowfinal_ab.txt): with runs of blocks
+// per die the eight dies stream eight distant regions of a plane instead of one front.
+#define DSX_RF_XCD 0
+#endif
 #ifndef DSX_INV_MINW
 #define DSX_INV_MINW 1  // waves per SIMD the fused uint16 final kernel is compiled for
 #endif
@@ -2470,7 +2476,16 @@ __global__ __launch_bounds__(64 * kRfWaves, CPL <= 18 ? 4 : 2) void k_rowfinal(R
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int M = StaticFft<PLAN_>::M;
   const int plane = blockIdx.y;
-  const int pair0 = (kRfWaves - 1) * blockIdx.x;  // first row pair of the block; its coefficient rows start at 2 pair0
+  // DSX_RF_XCD (off, see the switch): workgroup i of a launch runs on compute die i mod 8 (each die has its own L2).
+  // Neighbouring blocks of a plane share rows -- the row pair both filter, 2 of the 10 level-2 rows -- so the blocks
+  // of one die are made neighbours: die d takes the d-th run of gridDim.x / 8 consecutive blocks.
+#if DSX_RF_XCD
+  const int per_die = gridDim.x >> 3;  // the host launches a multiple of 8 blocks per plane
+  const int bx = (blockIdx.x & 7) * per_die + (blockIdx.x >> 3);
+#else
+  const int bx = blockIdx.x;
+#endif
+  const int pair0 = (kRfWaves - 1) * bx;  // first row pair of the block; its coefficient rows start at 2 pair0
   rf_pair_body<CPL, GF_, NT_, HALO_, PLAN_, true>(a.r, dsx_smem, dsx_smem + (long long)M * (1 + wave), tid, 64 * kRfWaves, lane,
                                                   pair0 + wave, plane);
   const int np = (a.f.hout + 1) >> 1;
