@@ -258,7 +258,10 @@ hipError_t launch_rowfilter(const dsx::RowArgs& a_in, int npairs, int nb, hipStr
     attr_set[dev & 63] = true;
   }
   static const int force_wpb = getenv("DSX_ROW_WPB") ? atoi(getenv("DSX_ROW_WPB")) : 0;
-  const int wpb = force_wpb ? force_wpb : ((CPL > 18) ? 4 : rowfilter_waves_per_block(a_in.M));
+  // M >= 1024 (level 2 of the hot shapes, 77 KB per 8-wave block): 4-wave blocks of 43 KB.  Alone the kernel does not
+  // care; beside the 74 KB blocks of k_rowfinal and the small coarse-level blocks three of them still find room on a CU
+  // where two of the big ones do not (+0.6 % 4-stream, +1.3 % single-stream, gpurun_out/wpb_sweep.txt)
+  const int wpb = force_wpb ? force_wpb : ((CPL > 18 || a_in.M >= 1024) ? 4 : rowfilter_waves_per_block(a_in.M));
   const size_t smem = (size_t)a_in.M * (wpb + 1) * sizeof(float2);
   const dsx::RowArgs& a = a_in;
   const dim3 grid((npairs + wpb - 1) / wpb, nb);

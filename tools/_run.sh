@@ -1,4 +1,8 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "fused_rowfinal" > gpurun_out/x1_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/x1_tests.log
-bash tools/ab.sh x1 rf1 2>&1 | tail -12
-bash tools/traffic.sh x1 > /dev/null 2>&1; grep "mb_per_plane\|rowfinal" gpurun_out/x1_traffic.json
+OUT=gpurun_out/wpb_sweep.txt; : > $OUT
+for round in 1 2 3 4 5; do
+  for v in "" "DSX_ROW_WPB=4" "DSX_ROW_WPB=2" "DSX_STREAMS=1" "DSX_STREAMS=1 DSX_ROW_WPB=4" "DSX_STREAMS=1 DSX_ROW_WPB=2"; do
+    r=$(env $v timeout -k 10 120 python bench.py --steps 100 --warmup 20 --cpu-planes 0 --settle 0.3 --no-verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+    echo "[$v] $r" | tee -a $OUT
+  done
+done
