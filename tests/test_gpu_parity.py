@@ -708,7 +708,11 @@ def test_fused_rowfinal_is_bit_identical_to_the_unfused_chain(monkeypatch):
     split over the four streams, with and without the shading epilogue, a plane of constant rows, a plane with the
     cells config, and a short plane (2048 wide, 200 high: the last block is partial)."""
     for h, w, n, shading in ((2048, 2048, 72, False), (2048, 2048, 20, True), (200, 2048, 40, False),
-                             (1600, 2000, 40, False), (1600, 2000, 20, True), (1800, 1800, 40, False)):
+                             (1600, 2000, 40, False), (1600, 2000, 20, True), (1800, 1800, 40, False), (2048, 2048, 16, None)):
+        # shading None: the cells config filters NO level (level 0 -> result x + 2 for its planes), the other one all of
+        # them -- level 1 is inactive for some planes of the cohort and k_rowfinal must synthesise rows of zeros for them
+        cells_cfg = dict(synth.CELLS_CONFIG, level=0) if shading is None else synth.CELLS_CONFIG
+        shading = bool(shading)
         bank = synth.synthetic_bank(6, h, w)
         flatp = np.full((h, w), 300, np.uint16)
         rows = np.repeat((100 + 50 * np.arange(h, dtype=np.uint16) % 7)[:, None], w, axis=1).astype(np.uint16)
@@ -724,7 +728,7 @@ def test_fused_rowfinal_is_bit_identical_to_the_unfused_chain(monkeypatch):
             monkeypatch.setenv("DSX_NO_FUSE_RF", mode)
             e = eng_mod.DestripeEngine(0)
             try:
-                e.plan(h, w, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT, max_batch=n,
+                e.plan(h, w, cells_cfg, synth.NO_CELLS_CONFIG, synth.ZARR_PATH_HIGH_INT, max_batch=n,
                        flatfield=flat, darkfield=dark)
                 small = e.run(stack[:8], out_dtype=np.uint16)            # one part, helper stream
                 big, cfg = e.run(stack, out_dtype=np.uint16, return_cfg=True)
@@ -734,7 +738,10 @@ def test_fused_rowfinal_is_bit_identical_to_the_unfused_chain(monkeypatch):
         assert res["0"][2].sum() > 0  # some planes took the cells config
         for a, b in zip(res["0"], res["1"]):
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b), err_msg=str((h, w, n, shading)))
-        if h == 2048 and not shading:  # and the reference: plane 1 of the stack against the oracle
+        if cells_cfg is not synth.CELLS_CONFIG:  # planes that chose the level-0 config come out as x + 2
+            for k in np.nonzero(res["0"][2])[0][:3]:
+                np.testing.assert_array_equal(res["0"][1][k], np.minimum(stack[k].astype(np.int64) + 2, 65535).astype(np.uint16))
+        elif h == 2048 and not shading:  # and the reference: plane 1 of the stack against the oracle
             ref = orc.filter_stripes(stack[1], "t", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT)
             d = np.abs(res["0"][1][1].astype(np.int64) - ref.astype(np.uint16).astype(np.int64))
             assert d.max() <= 1
