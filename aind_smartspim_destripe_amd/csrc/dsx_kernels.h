@@ -1549,12 +1549,18 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
         fhi[r] = (float)chi[r] - target;
       }
     }
-    for (int it = 0; it < 200 && !(done[0] && done[1]); ++it) {
+    // A row is finished when one element -- or, for ties, one value -- is left: C(hi) - C(lo) <= 1, or lo and hi are
+    // adjacent floats.  The second test needs the integer keys and is only made where they are computed anyway: on the
+    // fallback path (a probe strictly inside (lo, hi) proves that the two are not adjacent).  A finished row simply
+    // keeps running until its partner is finished too -- every step preserves C(lo) <= k < C(hi) -- so the loop body
+    // carries no per-row "done" predicates (they were most of its ~240 scalar instructions per step).
+    bool adj[2] = {done[0], done[1]};
+    for (int it = 0; it < 256; ++it) {
+      const bool fin0 = adj[0] || chi[0] - clo[0] <= 1u, fin1 = adj[1] || chi[1] - clo[1] <= 1u;
+      if (fin0 && fin1) break;
       float t[2];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const unsigned kl = f32_key(lo[r]), kh = f32_key(hi[r]);
-        if (!done[r] && (chi[r] - clo[r] <= 1u || kh - kl <= 1u)) done[r] = true;
         // false position aimed at rank k + 1/2 (the probe only has to lie inside the bracket: the bare v_rcp_f32 instead
         // of an IEEE division -- 12 instructions each -- changes which values are probed, never the result); on every
         // eighth step, and whenever it leaves the bracket, the midpoint of the integer keys halves the number of
@@ -1562,26 +1568,26 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
         // every fourth step took 9.75 counts per masked row of the synthetic planes, this takes 8.96 (NumPy model of both
         // loops against np.median on real and adversarial rows: tools/median_model.py)
         float tt = (lo[r] * fhi[r] - hi[r] * flo[r]) * __builtin_amdgcn_rcpf(fhi[r] - flo[r]);
-        const float tm = key_f32(kl + ((kh - kl) >> 1));
-        if ((it & 7) == 7 || !(tt > lo[r] && tt < hi[r])) tt = tm;
-        t[r] = done[r] ? lo[r] : tt;
+        if ((it & 7) == 7 || !(tt > lo[r] && tt < hi[r])) {  // wave-uniform
+          const unsigned kl = f32_key(lo[r]), kh = f32_key(hi[r]);
+          if (kh - kl <= 1u) adj[r] = true;
+          tt = key_f32(kl + ((kh - kl) >> 1));
+        }
+        t[r] = tt;
       }
-      if (done[0] && done[1]) break;
       const unsigned c = count2(t[0], t[1], false);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const unsigned cr = r ? (c >> 16) : (c & 0xFFFFu);
-        if (!done[r]) {
-          const float f = (float)cr - target;
-          if (cr <= k1) {
-            lo[r] = t[r]; clo[r] = cr; flo[r] = f;
-            if (last[r] == 1) fhi[r] *= 0.5f;
-            last[r] = 1;
-          } else {
-            hi[r] = t[r]; chi[r] = cr; fhi[r] = f;
-            if (last[r] == 2) flo[r] *= 0.5f;
-            last[r] = 2;
-          }
+        const float f = (float)cr - target;
+        if (cr <= k1) {
+          lo[r] = t[r]; clo[r] = cr; flo[r] = f;
+          if (last[r] == 1) fhi[r] *= 0.5f;
+          last[r] = 1;
+        } else {
+          hi[r] = t[r]; chi[r] = cr; fhi[r] = f;
+          if (last[r] == 2) flo[r] *= 0.5f;
+          last[r] = 2;
         }
       }
     }

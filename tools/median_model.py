@@ -122,3 +122,54 @@ def kernel_median2(x, thr, mode="illinois", safety=8):
         sk1 = sk if (k1 + 1 < chi) else nxt
     med = np.float32(0.5) * (sk + sk1) if even else sk
     return med, ncount
+
+
+def kernel_median3(x, thr, extra=0):
+    """Round-3 loop as shipped: Illinois false position, adjacency of lo / hi only tested on the fallback path, and a
+    finished row keeps stepping while its partner is not finished (`extra` more steps here) -- the invariant
+    C(lo) <= k < C(hi) must survive that."""
+    x = x.astype(np.float32); N = x.size
+    k1 = (N - 1) >> 1; even = (N & 1) == 0
+    ncount = 0
+    def C(t, le=False):
+        nonlocal ncount; ncount += 1
+        return int((x <= t).sum()) if le else int((x < t).sum())
+    lt = C(np.float32(0)); le = C(np.float32(0), True)
+    thr = np.float32(thr)
+    thr_up = (thr.view(np.uint32) + np.uint32(1)).view(np.float32)
+    adj = False
+    if k1 < lt: lo, clo, hi, chi = -thr, 0, np.float32(0), lt
+    elif k1 < le: lo, clo, hi, chi = np.float32(0), lt, np.uint32(1).view(np.float32), le; adj = True
+    else: lo, clo, hi, chi = np.uint32(1).view(np.float32), le, thr_up, N
+    target = np.float32(k1) + np.float32(0.5)
+    flo = np.float32(clo) - target; fhi = np.float32(chi) - target
+    last = 0; it = 0; extra_left = extra
+    with np.errstate(all="ignore"):
+        while it < 256:
+            if adj or chi - clo <= 1:
+                if extra_left == 0: break
+                extra_left -= 1
+            tt = np.float32(np.float32(lo * fhi - hi * flo) * (np.float32(1) / np.float32(fhi - flo)))
+            if (it & 7) == 7 or not (tt > lo and tt < hi):
+                kl, kh = f32_key(lo), f32_key(hi)
+                if int(kh) - int(kl) <= 1: adj = True
+                tt = key_f32(np.uint32(int(kl) + ((int(kh) - int(kl)) >> 1)))
+            c = C(tt)
+            f = np.float32(c) - target
+            if c <= k1:
+                lo, clo, flo = tt, c, f
+                if last == 1: fhi = np.float32(fhi * 0.5)
+                last = 1
+            else:
+                hi, chi, fhi = tt, c, f
+                if last == 2: flo = np.float32(flo * 0.5)
+                last = 2
+            it += 1
+    assert clo <= k1 < chi
+    sk = x[x >= lo].min()
+    sk1 = sk
+    if even:
+        nxt = x[x >= hi].min() if (x >= hi).any() else np.float32(np.inf)
+        sk1 = sk if (k1 + 1 < chi) else nxt
+    med = np.float32(0.5) * (sk + sk1) if even else sk
+    return med, ncount
