@@ -143,6 +143,28 @@ __device__ __forceinline__ float wave_min_f32(float v) {
   return v;
 }
 
+// min of two floats that are never NaN, as ONE v_min_f32.  fminf() on a value that comes out of memory (or a select of
+// one) makes the compiler quiet a possible signalling NaN first (v_max_f32 x, x, x per operand: 94 of them in the median's
+// last pass before this).
+__device__ __forceinline__ float min_no_nan(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// Wave minimum of values that are never NaN; the result is wave-uniform.  Four DPP steps inside the rows of 16 lanes
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: every lane then holds its row's minimum), then the four
+// rows through v_readlane -- no LDS crossbar (__shfl_xor is ds_bpermute_b32 + a wait per step).
+__device__ __forceinline__ float wave_min_no_nan(float v) {
+  v = min_no_nan(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = min_no_nan(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  v = min_no_nan(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+  v = min_no_nan(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+
 // Compiler-level + wavefront-scope ordering of LDS traffic inside ONE wave (no s_barrier):
 // the hardware executes a wave's LDS instructions in order; this keeps the compiler from
 // forwarding or reordering accesses across the point where other lanes' data is exchanged.
@@ -1594,20 +1616,20 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
     // s_k = min{x >= lo};  even N: s_{k+1} = s_k if more than k + 1 values lie below hi, else min{x >= hi}
     float m_lo[2] = {__builtin_huge_valf(), __builtin_huge_valf()}, m_hi[2] = {__builtin_huge_valf(), __builtin_huge_valf()};
     for_slots<GV>(gf, nt, [&](int e) {
-      m_lo[0] = fminf(m_lo[0], va[e] >= lo[0] ? va[e] : __builtin_huge_valf());
-      m_lo[1] = fminf(m_lo[1], vb[e] >= lo[1] ? vb[e] : __builtin_huge_valf());
+      m_lo[0] = min_no_nan(m_lo[0], va[e] >= lo[0] ? va[e] : __builtin_huge_valf());
+      m_lo[1] = min_no_nan(m_lo[1], vb[e] >= lo[1] ? vb[e] : __builtin_huge_valf());
       if (even) {
-        m_hi[0] = fminf(m_hi[0], va[e] >= hi[0] ? va[e] : __builtin_huge_valf());
-        m_hi[1] = fminf(m_hi[1], vb[e] >= hi[1] ? vb[e] : __builtin_huge_valf());
+        m_hi[0] = min_no_nan(m_hi[0], va[e] >= hi[0] ? va[e] : __builtin_huge_valf());
+        m_hi[1] = min_no_nan(m_hi[1], vb[e] >= hi[1] ? vb[e] : __builtin_huge_valf());
       }
     });
     float sk[2], sk1[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      sk[r] = wave_min_f32(m_lo[r]);
+      sk[r] = wave_min_no_nan(m_lo[r]);
       sk1[r] = sk[r];
       if (even) {
-        const float nxt = wave_min_f32(m_hi[r]);
+        const float nxt = wave_min_no_nan(m_hi[r]);
         sk1[r] = (k1 + 1u < chi[r]) ? sk[r] : nxt;
       }
     }
