@@ -454,26 +454,35 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
 #else
   constexpr int skip_hist = 0, skip_row = 0, skip_from = 1000;
 #endif
-  auto hist_level = [&](int l, hipStream_t hs) -> int {
-    if ((skip_hist >> l) & 1) return DSX_OK;
-    const dsx::LevelPlan& lp = p.lv[l];
+  // histograms of levels [l0, l1) in ONE launch (k_hist finds its level from the block index)
+  auto hist_levels = [&](int l0, int l1, hipStream_t hs) -> int {
     dsx::HistArgs a;
+    memset(&a, 0, sizeof(a));
     a.ws = v.ws;
     a.ws_plane_stride = p.plane_floats;
-    a.da_off = lp.da_off;
-    a.h = lp.h; a.w = lp.w; a.ld = lp.ld;
     a.minmax = v.minmax;
     a.hist = v.hist;
-    a.lvl = l; a.L = L;
+    a.L = L;
     a.shared = ctx->stack_mode ? 1 : 0;
-    // rows per block: each block zeroes and folds 32 KB of counters, so big cohorts take tall blocks (128 rows: + 1-2 %
-    // in the 4-stream run against 32), small ones keep enough blocks to spread over the chip (~512 per launch)
-    static const int hist_rows = getenv("DSX_HIST_ROWS") ? atoi(getenv("DSX_HIST_ROWS")) : 0;
-    const int auto_rows = std::max(32, std::min(128, (int)((long long)lp.h * nb / 512)));
-    a.rows_per_block = std::max(1, std::min(hist_rows > 0 ? hist_rows : auto_rows, 256));  // (16-bit per-lane counters: see k_hist)
-    dim3 grid((lp.h + a.rows_per_block - 1) / a.rows_per_block, nb);
+    int blocks = 0;
+    for (int l = l0; l < l1 && l < skip_from; ++l) {
+      if ((skip_hist >> l) & 1) continue;
+      const dsx::LevelPlan& lp = p.lv[l];
+      const int i = a.nlev++;
+      a.lvl[i] = l;
+      a.da_off[i] = lp.da_off;
+      a.h[i] = lp.h; a.w[i] = lp.w; a.ld[i] = lp.ld;
+      // rows per block: each block zeroes and folds 32 KB of counters, so big cohorts take tall blocks (128 rows: + 1-2 %
+      // in the 4-stream run against 32), small ones keep enough blocks to spread over the chip (~512 per launch)
+      static const int hist_rows = getenv("DSX_HIST_ROWS") ? atoi(getenv("DSX_HIST_ROWS")) : 0;
+      const int auto_rows = std::max(32, std::min(128, (int)((long long)lp.h * nb / 512)));
+      a.rows_per_block[i] = std::max(1, std::min(hist_rows > 0 ? hist_rows : auto_rows, 256));  // (16-bit per-lane counters: see k_hist)
+      blocks += (lp.h + a.rows_per_block[i] - 1) / a.rows_per_block[i];
+      a.blk_end[i] = blocks;
+    }
+    if (a.nlev == 0) return DSX_OK;
     LaunchScope ls(ctx, KC_HIST);
-    hipLaunchKernelGGL(dsx::k_hist, grid, dim3(64 * dsx::kHistWaves), 0, hs, a);
+    hipLaunchKernelGGL(dsx::k_hist, dim3(blocks, nb), dim3(64 * dsx::kHistWaves), 0, hs, a);
     DSX_HIP(hipGetLastError());
     return DSX_OK;
   };
@@ -561,15 +570,13 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     if (split && l == 0) {  // levels 1 and 2 are complete: their histograms start now, on the helper stream
       DSX_HIP(hipEventRecord(v.ev[0], s));
       DSX_HIP(hipStreamWaitEvent(v.helper, v.ev[0], 0));
-      if (int rc = hist_level(0, v.helper)) return rc;
-      if (int rc = hist_level(1, v.helper)) return rc;
+      if (int rc = hist_levels(0, 2, v.helper)) return rc;
       DSX_HIP(hipEventRecord(v.ev[1], v.helper));
     }
   }
 
   // ---- thresholds -----------------------------------------------------------------------------
-  for (int l = split ? 2 : 0; l < L && l < skip_from; ++l)
-    if (int rc = hist_level(l, s)) return rc;
+  if (int rc = hist_levels(split ? 2 : 0, L, s)) return rc;
   if (split) DSX_HIP(hipStreamWaitEvent(s, v.ev[1], 0));  // histograms of levels 1, 2 (helper stream)
   if (L > 0) {
     dsx::OtsuArgs a;

@@ -889,16 +889,21 @@ __global__ __launch_bounds__(64 * WPB, (FUSE && IN_KIND == 0) ? DSX_FWD_MINW : 1
 // ================================================================================================
 // K2: histogram of q = cH^2, numpy.histogram(bins=256) rule in float32
 // ================================================================================================
+// One launch covers SEVERAL levels (round 3: the eight histograms of a chain were eight launches, six of them a few
+// microseconds of work behind a launch gap each): block x of the grid belongs to the first entry i with x < blk_end[i].
 struct HistArgs {
   const float* ws;
   long long ws_plane_stride;
-  long long da_off;
-  int h, w, ld;
   const unsigned* minmax;
   unsigned* hist;  // [B][L][256]
-  int lvl, L;
-  int rows_per_block;
+  int L;
   int shared;  // stack mode: plane 0's min / max and histogram slots for every plane (Fwd1Args::shared)
+  int nlev;    // entries below
+  int lvl[kMaxLevels];             // level index of the entry
+  long long da_off[kMaxLevels];
+  int h[kMaxLevels], w[kMaxLevels], ld[kMaxLevels];
+  int rows_per_block[kMaxLevels];
+  int blk_end[kMaxLevels];         // cumulative block counts
 };
 
 // Bin of q = largest i with edges[i] <= q (numpy's estimate-then-correct rule ends there too).
@@ -931,12 +936,21 @@ constexpr int kHistLoads = 8;  // 16-byte loads in flight per lane
 
 constexpr int kHistWaves = 8;  // waves per block: they share one 32 KB counter array (LDS is what the 4-stream mix runs short of)
 
-__global__ __launch_bounds__(64 * kHistWaves) void k_hist(HistArgs a) {
+__global__ __launch_bounds__(64 * kHistWaves) void k_hist(HistArgs args) {
   __shared__ __attribute__((aligned(16))) unsigned s_cnt[256 * 32];
   __shared__ float s_edge[264];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int plane = blockIdx.y;
+  // the entry of this block (block-uniform, scalar unit)
+  int ent = 0;
+  while (ent + 1 < args.nlev && (int)blockIdx.x >= args.blk_end[ent]) ++ent;
+  struct {
+    const float* ws; long long ws_plane_stride, da_off; int h, w, ld, lvl, L, rows_per_block, shared;
+    const unsigned* minmax; unsigned* hist;
+  } a = {args.ws, args.ws_plane_stride, args.da_off[ent], args.h[ent], args.w[ent], args.ld[ent], args.lvl[ent], args.L,
+         args.rows_per_block[ent], args.shared, args.minmax, args.hist};
+  const int bx = (int)blockIdx.x - (ent > 0 ? args.blk_end[ent - 1] : 0);
   const int splane = a.shared ? 0 : plane;
   const unsigned* mm = a.minmax + ((long long)splane * a.L + a.lvl) * 2;
   const float qmin = as_f32(~mm[0]), qmax = as_f32(mm[1]);
@@ -961,7 +975,7 @@ __global__ __launch_bounds__(64 * kHistWaves) void k_hist(HistArgs a) {
     atomicAdd((unsigned*)((char*)s_cnt + ((unsigned)idx * 128u + lane_off)), inc);
   };
   const float* da = a.ws + plane * a.ws_plane_stride + a.da_off;
-  const int r0 = blockIdx.x * a.rows_per_block;
+  const int r0 = bx * a.rows_per_block;
   const int nrows = min(a.h, r0 + a.rows_per_block) - r0;
   // ---- full 256-column chunks: item = (row, chunk), dealt round robin to the four waves, kHistLoads at a time ----
   const int gf = a.w >> 8;
