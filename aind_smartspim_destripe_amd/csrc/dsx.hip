@@ -355,6 +355,29 @@ hipError_t launch_rowfinal(int plan, const dsx::RowFinalArgs& a, int nb, hipStre
   return hipErrorInvalidValue;
 }
 
+// Levels whose row filters all fit the CPL = 6 class, in ONE launch (k_rowfilter_multi).
+hipError_t launch_rowfilter_multi(const dsx::RowMultiArgs& a_in, const int* npairs, int nb, hipStream_t s) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)dsx::k_rowfilter_multi<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev & 63] = true;
+  }
+  const int wpb = dsx::kRowMaxWaves;
+  dsx::RowMultiArgs a = a_in;
+  int blocks = 0, max_m = 1;
+  for (int i = 0; i < a.nlev; ++i) {
+    blocks += (npairs[i] + wpb - 1) / wpb;
+    a.blk_end[i] = blocks;
+    max_m = std::max(max_m, a.lv[i].M);
+  }
+  const size_t smem = (size_t)max_m * (wpb + 1) * sizeof(float2);
+  hipLaunchKernelGGL(dsx::k_rowfilter_multi<6>, dim3(blocks, nb), dim3(64 * wpb), smem, s, a);
+  return hipGetLastError();
+}
+
 // Row segmentation of the marching kernels: enough waves to fill the chip for small cohorts,
 // one segment per strip for large ones (each extra segment re-reads a 4-row halo).
 // wpb > 0 (the fused level-1 kernels, wpb waves per block, 16 waves per CU): the segment count is also chosen against
@@ -614,6 +637,11 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   }
   dsx::RowArgs row1;  // level 1, for k_rowfinal
   memset(&row1, 0, sizeof(row1));
+  // coarse levels (M <= 384) that run on the part's own stream: one launch for all of them (DSX_NO_ROW_MULTI=1: one each)
+  static const bool no_multi = getenv("DSX_NO_ROW_MULTI") && atoi(getenv("DSX_NO_ROW_MULTI")) != 0;
+  dsx::RowMultiArgs multi;
+  memset(&multi, 0, sizeof(multi));
+  int multi_pairs[dsx::kRowMultiMax] = {};
   for (int l = 0; l < L && l < skip_from; ++l) {
     hipStream_t rs = (split_inv && l < 2) ? v.helper : s;
     if ((skip_row >> l) & 1) continue;
@@ -644,8 +672,23 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
       continue;
     }
     const int npairs = (lp.h + 1) / 2;
+    // (only for cohorts split over the streams, where the launch gaps of six small kernels cost more than the
+    //  specialised CPL = 2 / 4 instantiations save: +2.4 % there, -5 % for a cohort that runs alone -- its coarse chain
+    //  is the critical path beside the level-2 row filter on the helper stream; profiles/r3_merged_small_launches_ab.txt)
+    if (!no_multi && !v.alone && rs == s && a.M <= 6 * 64 && multi.nlev < dsx::kRowMultiMax) {
+      multi_pairs[multi.nlev] = npairs;
+      multi.lv[multi.nlev++] = a;
+      continue;
+    }
     LaunchScope ls(ctx, KC_ROW);
     DSX_HIP(dispatch_rowfilter(a, npairs, nb, rs));
+  }
+  if (multi.nlev == 1) {
+    LaunchScope ls(ctx, KC_ROW);
+    DSX_HIP(dispatch_rowfilter(multi.lv[0], multi_pairs[0], nb, s));
+  } else if (multi.nlev > 1) {
+    LaunchScope ls(ctx, KC_ROW);
+    DSX_HIP(launch_rowfilter_multi(multi, multi_pairs, nb, s));
   }
   if (split_inv) DSX_HIP(hipEventRecord(v.ev[3], v.helper));
   if (ctx->stop_after == 2) return DSX_OK;

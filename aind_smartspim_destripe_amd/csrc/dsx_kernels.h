@@ -1784,6 +1784,28 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
                                                    blockIdx.x * (blockDim.x >> 6) + wave, blockIdx.y);
 }
 
+// The row filters of SEVERAL coarse levels in one launch (round 3): levels 3 ... 8 of a 2048^2 plane are six launches of
+// a few hundred to a few thousand row pairs, each behind a launch gap; their rows all fit the CPL = 6 class (M <= 384),
+// so one grid carries them all and every block picks the RowArgs of its level from the block index.
+constexpr int kRowMultiMax = 8;
+struct RowMultiArgs {
+  int nlev;
+  int blk_end[kRowMultiMax];  // cumulative block counts
+  RowArgs lv[kRowMultiMax];
+};
+
+template <int CPL>
+__global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void k_rowfilter_multi(RowMultiArgs args) {
+  extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int ent = 0;
+  while (ent + 1 < args.nlev && (int)blockIdx.x >= args.blk_end[ent]) ++ent;  // block-uniform, scalar unit
+  const RowArgs& a = args.lv[ent];
+  const int bx = (int)blockIdx.x - (ent > 0 ? args.blk_end[ent - 1] : 0);
+  rf_pair_body<CPL, -1, -1, -1, 0, false>(a, dsx_smem, dsx_smem + (long long)a.M * (1 + wave), tid, blockDim.x, lane,
+                                          bx * (blockDim.x >> 6) + wave, blockIdx.y);
+}
+
 // ================================================================================================
 // K5/K6: synthesis level, "marching" form.  One wave owns 256 result columns (4 per lane)
 // and streams down the coefficient rows p: the row (axis-1) synthesis of c_1 / Delta_1 is done
