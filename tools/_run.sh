@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_wavelets.py -m gpu -x -q > gpurun_out/r1_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r1_tests.log
-bash tools/ab.sh r1 r0 2>&1 | tail -12
+L=$PWD/aind_smartspim_destripe_amd/_lib
+for v in c0 cw8 cw4 hip; do echo "== $v"; DSX_LIB=$L/libdsx_$v.so timeout -k 10 200 python tools/latency_small.py 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print(d['planes'], d['latency_us'], d['back_to_back_us'], d['planes_per_s'])"; done | tee gpurun_out/c3_latency.txt
