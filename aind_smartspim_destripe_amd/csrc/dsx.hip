@@ -675,7 +675,10 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     // (only for cohorts split over the streams, where the launch gaps of six small kernels cost more than the
     //  specialised CPL = 2 / 4 instantiations save: +2.4 % there, -5 % for a cohort that runs alone -- its coarse chain
     //  is the critical path beside the level-2 row filter on the helper stream; profiles/r3_merged_small_launches_ab.txt)
-    if (!no_multi && !v.alone && rs == s && a.M <= 6 * 64 && multi.nlev < dsx::kRowMultiMax) {
+    // ... and small cohorts that run alone are launch-bound again: one plane 418 -> 358 us per call, 32 planes + 7 %,
+    // 64 planes even, 128 planes - 2.7 % (profiles/r3_merged_small_launches_ab.txt); DSX_ROW_MULTI_ALONE = the limit
+    static const int multi_alone = getenv("DSX_ROW_MULTI_ALONE") ? atoi(getenv("DSX_ROW_MULTI_ALONE")) : 48;
+    if (!no_multi && (!v.alone || nb <= multi_alone) && rs == s && a.M <= 6 * 64 && multi.nlev < dsx::kRowMultiMax) {
       multi_pairs[multi.nlev] = npairs;
       multi.lv[multi.nlev++] = a;
       continue;
