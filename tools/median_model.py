@@ -61,7 +61,7 @@ def kernel_median(x, thr, strategy="cur"):
     med = np.float32(0.5) * (sk + sk1) if even else sk
     return med, ncount
 
-if __name__ == "__main__":
+if __name__ == "__main__":  # pragma: no cover
     from parity_util import oracle_plane
     tot = {}
     for k in (1, 4):
