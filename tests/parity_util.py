@@ -215,7 +215,11 @@ def check_plane(out, img, deltas, what, cfg, max_flips, ref=None, stages=None, p
         rel_f = rel_err(out, ref_f)
         assert float(rel_f.max()) < REL_TOL, (what, "beyond 1e-4 with identical mask decisions", float(rel_f.max()),
                                               int((rel_f >= REL_TOL).sum()))
-    assert float(np.median(rel)) < 1e-5, (what, float(np.median(rel)))
+    # tripwire for a systematic bias: the typical pixel agrees to float32 round-off -- GIVEN the same decisions.  (A flipped
+    # coefficient of a coarse level moves more than half of a small plane by ~1e-5, below the tolerance but above this
+    # bound: fuzz case 199 of seed 424242, where the reference's own float32 and float64 regimes differ by exactly that.)
+    rel_typ = rel if forced is None else rel_f
+    assert float(np.median(rel_typ)) < 1e-5, (what, float(np.median(rel_typ)))
     print("[parity] {}: flips per level {}, {} px beyond 1e-4 vs the unforced reference (max {:.2e}){}{}".format(
         what, flips, n_bad, float(rel.max()), "" if forced is None else "; strict with the flips forced",
         "" if not tie_levels else "; Otsu tie at level index {} (engine's bin taken in the oracle)".format(tie_levels)))
