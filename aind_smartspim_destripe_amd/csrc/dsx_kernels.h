@@ -1908,7 +1908,12 @@ __device__ __forceinline__ float final_px(const FinalArgs& a, float c0l, float x
   float v = fmaf(1.0f + x, __builtin_amdgcn_exp2f(c0l), 1.0f);  // exp(log(1 + x) + c0) + 1  (filtering.py:222)
   if (SHADE) {                                                    // flatfield_correction, filtering.py:399-412
     v = (v > dark) ? (v - dark) : 0.f;
-    v = v / flat;
+    // v / flat as reciprocal, product, one residual correction and the fix-up instruction of the division sequence
+    // (zero / infinite / NaN operands come out as the IEEE quotient): 5 instructions where the full sequence has 11,
+    // which was a fifth of this epilogue.  Differs from the correctly rounded quotient by at most one ulp, rarely.
+    const float rc = __builtin_amdgcn_rcpf(flat);
+    const float q = v * rc;
+    v = __builtin_amdgcn_div_fixupf(fmaf(fmaf(-q, flat, v), rc, q), flat, v);
     v = fminf(fmaxf(v, 0.f), 65535.f);
   }
   return v;
