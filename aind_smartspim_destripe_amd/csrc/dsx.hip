@@ -269,8 +269,25 @@ hipError_t launch_rowfilter(const dsx::RowArgs& a_in, int npairs, int nb, hipStr
   return hipGetLastError();
 }
 
+// rows longer than one wave holds: one 512-lane block per row pair, the row buffer is the block's LDS
+hipError_t launch_rowfilter_wide(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)dsx::k_rowfilter_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(dsx::kWideMaxLen * sizeof(float2)));
+    if (e != hipSuccess) return e;
+    attr_set[dev & 63] = true;
+  }
+  if (a.M > dsx::kWideMaxLen || a.w >= 65536) return hipErrorInvalidValue;  // (the plan refuses these lengths)
+  hipLaunchKernelGGL(dsx::k_rowfilter_wide, dim3(npairs, nb), dim3(dsx::kWideThreads), (size_t)a.M * sizeof(float2), s, a);
+  return hipGetLastError();
+}
+
 hipError_t dispatch_rowfilter(const dsx::RowArgs& a, int npairs, int nb, hipStream_t s) {
   const int cpl = (a.M + 63) / 64;
+  if (cpl > 36) return launch_rowfilter_wide(a, npairs, nb, s);
   // slot structure of the row (full 256-value groups, 64-value tail slots) and pass list: the wide levels of
   // 2048-, 2000- and 1800-wide planes have instantiations with all of it as compile-time constants
   const int gf = a.w >> 8, nt = (a.w - (gf << 8) + 63) >> 6;

@@ -1806,6 +1806,238 @@ __global__ __launch_bounds__(64 * kRowMaxWaves, row_waves_per_simd<CPL>()) void 
                                           bx * (blockDim.x >> 6) + wave, blockIdx.y);
 }
 
+// ---- K4w: the row filter for rows longer than one wave holds (levels wider than 64 x 36 = 2 304 coefficients: planes
+// wider than ~4 600 pixels; round 3) -------------------------------------------------------------------------------
+// One BLOCK of kWideThreads lanes per pair of rows; the complex row buffer fills the block's LDS (up to 144 KiB), the
+// twiddles are read from global memory; the passes are those of k_rowfilter with the butterflies dealt to the whole
+// block and a block barrier where the wave kernel has a wave barrier.  The exact median is a 32-step bisection of the
+// order-preserving integer keys (both rows in lockstep, one block-wide count per step): simple and bounded; these
+// shapes are rare (no SmartSPIM camera is that wide) and the kernel is written for the reference's "any width"
+// (filtering.py:206), not for speed.  Same arithmetic as rf_pair_body everywhere else.
+constexpr int kWideThreads = 512;
+constexpr int kWideCpl = 36;                              // complex values per lane
+constexpr int kWideMaxLen = kWideThreads * kWideCpl;      // 18 432: transform lengths the kernel takes
+
+__device__ __forceinline__ unsigned wide_block_sum(unsigned v, unsigned* s_red, int& turn) {
+  v = __reduce_add_sync(~0ull, v);
+  unsigned* slot = s_red + ((turn & 1) ? (kWideThreads / 64) : 0);  // alternating halves: one barrier per reduction
+  if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned t = 0;
+#pragma unroll
+  for (int w = 0; w < kWideThreads / 64; ++w) t += slot[w];
+  ++turn;
+  return t;
+}
+__device__ __forceinline__ unsigned wide_block_min(unsigned v, unsigned* s_red, int& turn) {
+  v = __reduce_min_sync(~0ull, v);
+  unsigned* slot = s_red + ((turn & 1) ? (kWideThreads / 64) : 0);
+  if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned t = ~0u;
+#pragma unroll
+  for (int w = 0; w < kWideThreads / 64; ++w) t = min(t, slot[w]);
+  ++turn;
+  return t;
+}
+
+template <int R, int CPL, int JK = (R - 1) / 2>
+__device__ __forceinline__ void fft_pass_block(float2* buf, const float2* tw, int M, int s, float inv_s, int tid) {
+  constexpr int MAXB = (CPL + R - 1) / R;
+  const int nb = M / R;
+  const bool unit_tw = (s * R == M);
+  dsx_c32 v[MAXB][R];
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int b = tid + kWideThreads * i;
+    if (b < nb) dsx_bfly_load<R, JK>((const dsx_c32*)buf, b, nb, v[i]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int b = tid + kWideThreads * i;
+    if (b < nb) dsx_bfly_store<R, JK>((dsx_c32*)buf, (const dsx_c32*)tw, b, s, inv_s, v[i], unit_tw);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+}
+template <int CPL>
+__device__ __forceinline__ void fft_pass_generic_block(float2* buf, const float2* tw, int M, int s, float inv_s, int R,
+                                                       int tid) {
+  float2 acc[CPL];
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int o = tid + kWideThreads * i;
+    acc[i] = make_float2(0.f, 0.f);
+    if (o < M) {
+      const dsx_c32 r = dsx_generic_output((const dsx_c32*)buf, (const dsx_c32*)tw, o, M, s, inv_s, R);
+      acc[i] = make_float2(r.x, r.y);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int o = tid + kWideThreads * i;
+    if (o < M) buf[o] = acc[i];
+  }
+  __syncthreads();
+}
+template <int CPL>
+__device__ __forceinline__ void fft_run_block(float2* buf, const float2* tw, const RowArgs& a, int tid_in) {
+  int s = 1;
+  for (int pi = 0; pi < a.npass; ++pi) {
+    const int R = a.radix[pi];
+    const float inv_s = 1.0f / (float)s;
+    int tid = tid_in, M = a.M;
+    asm volatile("" : "+v"(tid), "+s"(M));  // (see fft_run)
+    switch (R) {
+      case 2: fft_pass_block<2, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 3: fft_pass_block<3, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 4: fft_pass_block<4, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 5: fft_pass_block<5, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 6: fft_pass_block<6, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 8: fft_pass_block<8, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 9: fft_pass_block<9, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 10: fft_pass_block<10, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 12: fft_pass_block<12, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 15: fft_pass_block<15, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 16: fft_pass_block<16, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 20: fft_pass_block<20, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 25: fft_pass_block<25, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 7: fft_pass_block<7, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 11: fft_pass_block<11, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 13: fft_pass_block<13, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 17: fft_pass_block<17, CPL>(buf, tw, M, s, inv_s, tid); break;
+      case 19: fft_pass_block<19, CPL>(buf, tw, M, s, inv_s, tid); break;
+      default: fft_pass_generic_block<CPL>(buf, tw, M, s, inv_s, R, tid); break;
+    }
+    s *= R;
+  }
+}
+
+__global__ __launch_bounds__(kWideThreads) void k_rowfilter_wide(RowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float2 dsx_smem[];  // [M]
+  __shared__ unsigned s_red[2 * (kWideThreads / 64)];
+  constexpr int E = kWideCpl;
+  float2* const buf = dsx_smem;
+  const int tid = threadIdx.x, plane = blockIdx.y, pair = blockIdx.x;
+  const int M = a.M, N = a.w, K = a.K;
+  const bool halo = K > 0;
+  const int r0 = 2 * pair;
+  const bool has_b = (r0 + 1) < a.h;
+  const int cfg = a.cfg[plane];
+  float* rowa = a.ws + plane * a.ws_plane_stride + a.da_off + (long long)r0 * a.ld;
+  float* rowb = rowa + a.ld;
+  if (a.lvl >= a.lvl_active[cfg]) {  // this config does not filter this level: Delta = 0 (block-uniform)
+    for (int n = tid; n < N; n += kWideThreads) {
+      rowa[n] = 0.f;
+      if (has_b) rowb[n] = 0.f;
+    }
+    return;
+  }
+  const float thr = a.thr[(long long)plane * a.L + a.lvl];
+  // background values (masked entries zeroed, filtering.py:195-197) as order-preserving keys; slots past the row: ~0
+  unsigned ka[E], kb[E];
+  unsigned long long maska = 0ull, maskb = 0ull;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int n = tid + kWideThreads * e;
+    ka[e] = kb[e] = ~0u;
+    if (n < N) {
+      const float xa = rowa[n], xb = has_b ? rowb[n] : 0.f;
+      const bool ma = fabsf(xa) > thr, mb = has_b && fabsf(xb) > thr;
+      if (ma) maska |= 1ull << e;
+      if (mb) maskb |= 1ull << e;
+      ka[e] = f32_key(ma ? 0.f : xa);
+      kb[e] = f32_key(mb ? 0.f : xb);
+    }
+  }
+  int turn = 0;
+  float meda = 0.f, medb = 0.f;
+  const bool any_mask = wide_block_sum((maska | maskb) != 0ull ? 1u : 0u, s_red, turn) != 0u;
+  if (any_mask) {  // (block-uniform) exact medians, np.median (filtering.py:201)
+    const unsigned k1 = (unsigned)(N - 1) >> 1;
+    auto count_below = [&](unsigned ta, unsigned tb) {  // (#a < ta) | (#b < tb) << 16 over the block (N < 65 536)
+      unsigned c = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) c += (ka[e] < ta ? 1u : 0u) + (kb[e] < tb ? 0x10000u : 0u);
+      return wide_block_sum(c, s_red, turn);
+    };
+    unsigned pa = 0u, pb = 0u;  // largest T with #{key < T} <= k1: the key of the element of rank k1
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned ta = pa | (1u << bit), tb = pb | (1u << bit);
+      const unsigned c = count_below(ta, tb);
+      if ((c & 0xFFFFu) <= k1) pa = ta;
+      if ((c >> 16) <= k1) pb = tb;
+    }
+    float ska = key_f32(pa), skb = key_f32(pb);
+    if ((N & 1) == 0) {  // even length: mean of the elements of rank k1 and k1 + 1
+      const unsigned cle = count_below(pa + 1u, pb + 1u);  // #{key <= P} (a valid key is < ~0)
+      unsigned na = ~0u, nb_ = ~0u;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (ka[e] > pa) na = min(na, ka[e]);
+        if (kb[e] > pb) nb_ = min(nb_, kb[e]);
+      }
+      na = wide_block_min(na, s_red, turn);
+      nb_ = wide_block_min(nb_, s_red, turn);
+      const float sa1 = ((cle & 0xFFFFu) >= k1 + 2u) ? ska : key_f32(na);
+      const float sb1 = ((cle >> 16) >= k1 + 2u) ? skb : key_f32(nb_);
+      meda = 0.5f * (ska + sa1);
+      medb = 0.5f * (skb + sb1);
+    } else {
+      meda = ska;
+      medb = skb;
+    }
+  }
+  // ---- in-painted rows -> complex buffer u[m] = x[(m - K) mod N], m in [0, N + 2K]; zero above ----------------------
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int n = tid + kWideThreads * e;
+    if (n < N) {
+      const float2 z = make_float2(((maska >> e) & 1ull) ? meda : key_f32(ka[e]), ((maskb >> e) & 1ull) ? medb : key_f32(kb[e]));
+      buf[K + n] = z;
+      if (halo) {
+        if (n <= K) buf[K + N + n] = z;
+        if (n >= N - K) buf[n - (N - K)] = z;
+      }
+    }
+  }
+  if (halo) {
+    for (int m = N + 2 * K + 1 + tid; m < M; m += kWideThreads) buf[m] = make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  fft_run_block<E>(buf, a.tw, a, tid);
+  {  // V[k] = G1[k] U[k] + G2[k] U[M - k], stored re/im-swapped (see rf_pair_body)
+    const float2* g1 = a.g[cfg];
+    const float2* g2 = g1 + M;
+    const int kcut = a.kcut[cfg];
+    for (int k = tid; k <= kcut; k += kWideThreads) {
+      const int kr = (k == 0) ? 0 : M - k;
+      const float2 u = buf[k], ur = buf[kr];
+      const float ga = g1[k].x;
+      const float2 gb = g2[k];
+      const float2 v = make_float2(ga * u.x + gb.x * ur.x - gb.y * ur.y, ga * u.y + gb.x * ur.y + gb.y * ur.x);
+      const float2 vr = make_float2(ga * ur.x + gb.x * u.x + gb.y * u.y, ga * ur.y + gb.x * u.y - gb.y * u.x);
+      buf[k] = make_float2(v.y, v.x);
+      if (kr != k) buf[kr] = make_float2(vr.y, vr.x);
+    }
+    for (int k = kcut + 1 + tid; k < M - kcut; k += kWideThreads) buf[k] = make_float2(0.f, 0.f);
+    __syncthreads();
+  }
+  fft_run_block<E>(buf, a.tw, a, tid);
+  // ---- Delta = -(1 - mask) LP (filtering.py:215-217): row a <- .y, row b <- .x ----------------------------------------
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int n = tid + kWideThreads * e;
+    if (n < N) {
+      const float2 y = buf[K + n];
+      rowa[n] = ((maska >> e) & 1ull) ? 0.f : -y.y * a.inv_M;
+      if (has_b) rowb[n] = ((maskb >> e) & 1ull) ? 0.f : -y.x * a.inv_M;
+    }
+  }
+}
+
 // ================================================================================================
 // K5/K6: synthesis level, "marching" form.  One wave owns 256 result columns (4 per lane)
 // and streams down the coefficient rows p: the row (axis-1) synthesis of c_1 / Delta_1 is done

@@ -23,6 +23,7 @@ constexpr int kPlanMaxLevels = 16;
 constexpr int kPlanMaxPasses = 16;
 constexpr int kFilterLen = 6;           // db3 (the default filter length of build_plan)
 constexpr int kMaxFftLen = 64 * 36;     // largest row-filter kernel instantiation (CPL = 36)
+constexpr int kMaxWideLen = 512 * 36;   // k_rowfilter_wide (one block per row pair): levels too long for one wave
 
 struct HostCfg {
   int level;  // -1 == maximum
@@ -250,11 +251,15 @@ inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p, int f
     //      smooth at k = 0 -- so the halo cannot be truncated below n / 2.)
     int best_m = n, best_k = 0;
     double best_cost = fft_cost(n);
-    if (n > kMaxFftLen) best_cost = 1e300;
+    // transforms longer than one wave holds run k_rowfilter_wide (one block per row pair; priced like the CPL = 36 class
+    // by fft_cost): rows of planes wider than ~4 600 px, and the embedding of a shorter row whose length has a large prime
+    // factor (n = 1283 at level 2 of a 5120-wide plane: a generic radix-1283 pass would cost 400 x the passes of 2 601)
+    const int max_len = kMaxWideLen;
+    if (n > max_len) best_cost = 1e300;
     if (n >= 8) {
       const int K = n / 2;
       const int need = n + 2 * K + 1;
-      for (int m = need; m <= std::min(2 * need, kMaxFftLen); ++m) {
+      for (int m = need; m <= std::min(2 * need, max_len); ++m) {
         int t = m;
         for (int q : {2, 3, 5, 7, 11, 13, 17, 19}) while (t % q == 0) t /= q;
         if (t != 1) continue;  // only lengths whose passes all have register butterflies

@@ -589,6 +589,36 @@ def test_fused_kernel_edge_shapes(engine, shape):
         engine.set_stop_after(0)
 
 
+@pytest.mark.parametrize(
+    "shape",
+    [
+        (40, 4604),    # level 1 has 2 304 coefficients per row: the last width the one-wave row filter takes
+        (40, 4608),    # 2 306: the first one k_rowfilter_wide takes (direct transform 2 * 1153 or embedded)
+        (33, 6001),    # odd width and height, levels 1 and 2 wide
+        (24, 9216),    # 4 610 = 2 * 5 * 461: embedded transform (a length of small primes, periodic halo)
+        (16, 12288),   # 6 146 = 2 * 7 * 439
+        (300, 5120),   # a camera-like plane: 8 levels, two of them wide
+        (40, 2304),    # 1 154 = 2 * 577 coefficients: fits a wave, but its embedding (2 340) does not -- block kernel
+    ],
+)
+def test_planes_wider_than_one_wave_holds(engine, shape):
+    """The reference takes any width (filtering.py:206); rows of more than 2 304 coefficients (planes wider than 4 604
+    pixels) run the block-per-row-pair row filter (k_rowfilter_wide: block-wide passes, key-bisection median).  Every
+    pixel of two planes against the oracle, uint16 and float32 input, both configs in play."""
+    planes = np.stack([synth.synthetic_plane(k, *shape) for k in (0, 1)])
+    for src in (planes, planes.astype(np.float32)):
+        deltas = gpu_deltas(engine, src)
+        out, cfg = filtering.destripe_planes(
+            src, "X_0_Y_0", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT,
+            out_dtype=np.float32, return_config=True, max_batch=2,
+        )  # fmt: skip
+        for k in range(2):
+            which, _, _, ref, stages = oracle_plane(src[k])
+            assert int(cfg[k]) == which
+            assert out[k].shape == ref.shape
+            _check_plane(out[k], src[k], deltas[k], (shape, k), ref=ref, stages=stages)
+
+
 def test_otsu_tie_plane(engine, capsys):
     """A plane whose level-2 class-variance curve has two maxima that agree to 1.5e-7 relative (found by
     tools/fuzz_parity.py): the reference's arg-max lands on bin 50, the engine's -- its float32 coefficients differ

@@ -57,7 +57,8 @@ def test_engine_fails_loudly_without_gpu(lib):
         filtering.log_space_fft_filtering(np.ones((16, 16), np.float32), level=1)
 
 
-@pytest.mark.parametrize("m", [1, 2, 4, 12, 20, 36, 42, 63, 68, 117, 126, 132, 144, 260, 515, 567, 960, 1026, 1071, 229, 1080, 1280, 1815, 2048, 2304])
+@pytest.mark.parametrize("m", [1, 2, 4, 12, 20, 36, 42, 63, 68, 117, 126, 132, 144, 260, 515, 567, 960, 1026, 1071, 229, 1080, 1280, 1815, 2048, 2304,
+                               3003, 4693, 9252])  # (the last three: lengths of k_rowfilter_wide, 9252 = 6 * 6 * 257 with a generic pass)
 def test_fft_core_against_naive_dft(host_check, m):
     r = host_check("fft", m)
     assert r["rel_err"] < 2e-6, r
@@ -90,10 +91,26 @@ def test_plan_geometry_matches_pywt(host_check):
     assert p["L"] == 0 and (p["Hout"], p["Wout"]) == (64, 64)
 
 
+def test_plan_of_planes_wider_than_one_wave_holds(host_check):
+    """Rows of more than 64 * 36 coefficients go to the block-per-row-pair kernel: transform lengths up to 512 * 36, direct
+    or embedded (periodic halo of half a row); beyond that the plan refuses the plane (DSX_ELIMIT)."""
+    p = host_check("plan", 40, 4604, 128, -1, 64, -1)
+    assert (p["levels"][0]["w"], p["levels"][0]["M"]) == (2304, 2304)
+    for (h, w), n in (((40, 4608), 2306), ((33, 6001), 3003), ((24, 9216), 4610), ((16, 12288), 6146), ((16, 18500), 9252),
+                      ((16, 36856), 18430)):
+        lv = host_check("plan", h, w, 128, -1, 64, -1)["levels"][0]
+        assert lv["w"] == n and 2304 < lv["M"] <= 512 * 36, (w, lv["M"])
+        assert int(np.prod(lv["radix"])) == lv["M"]
+        assert (lv["M"] == n and lv["K"] == 0) or (lv["K"] == n // 2 and lv["M"] >= 2 * n + 1), lv
+    with pytest.raises(subprocess.CalledProcessError) as ei:
+        host_check("plan", 16, 36900, 128, -1, 64, -1)
+    assert "too wide" in ei.value.stdout
+
+
 @pytest.mark.parametrize("args", [
     (2048, 2048, 64, -1, 0), (2048, 2048, 128, -1, 1), (2048, 2048, 64, -1, 4), (2048, 2048, 64, -1, 7),
     (1800, 1800, 64, -1, 1), (1800, 1800, 128, -1, 2), (1600, 2000, 128, -1, 1), (512, 512, 64, -1, 0),
-    (100, 100, 64, 1, 0),
+    (100, 100, 64, 1, 0), (16, 4608, 128, -1, 0), (16, 6001, 64, -1, 0),
 ])  # fmt: skip
 def test_row_filter_spectral_pipeline(host_check, args):
     """Two rows per complex FFT + G1/G2 tables (direct and exact-halo modes) reproduce the
