@@ -11,9 +11,12 @@
 // is the third-party c-blosc 1.x container; neither it nor numcodecs is installed here, but the image carries
 // libzstd.so.1 (and liblz4.so.1), so the container is restated from its published format (c-blosc README_HEADER.rst
 // / blosc.c: 16-byte header, block start table, per-block streams with an int32 length each, byte shuffle) and the
-// inner codecs are dlopen'ed.  PARITY UNPINNED: no file written by the real library exists in the reference or in
-// this image to check against -- tests cover round trips, hand-assembled frames (tests/test_formats.py builds them
-// in pure Python from the format description, incl. split blocks this writer never emits) and malformed input.
+// zstd / lz4 codecs are dlopen'ed; blosclz and the two shuffles are restated here.  PARITY PINNED (round 3): the image's
+// /opt/conda/lib/libblosc.so.1 is the real c-blosc 1.21.0 (numcodecs is not installed, the library it wraps is) --
+// oracle/make_golden_blosc.py wrote 77 frames with it (every inner codec of that build, no / byte / bit shuffle, type
+// sizes 1 ... 8, split and unsplit blocks, stored frames: tests/golden/blosc_frames.npz) which this reader must decode,
+// and tests/test_blosc.py hands this writer's frames to the real blosc_decompress_ctx where the library is present.
+// Also covered: round trips, hand-assembled frames (tests/test_formats.py) and malformed input (mutation check, ASan).
 // Pure C++ (no HIP): tests/host can build it with g++.
 #ifndef DSX_IO_H
 #define DSX_IO_H
@@ -210,6 +213,84 @@ inline void blosc_unshuffle(size_t typesize, size_t blocksize, const unsigned ch
   memcpy(dst + ne * typesize, src + ne * typesize, blocksize - ne * typesize);
 }
 
+// Inverse of c-blosc's bit shuffle (shuffle = BITSHUFFLE, the bitshuffle library's layout): with S = typesize and
+// N = elements of the block, the shuffled block holds S * 8 bit rows of N / 8 bytes -- row (s, b) = bit b of byte s of
+// every element, element 8 j + k in bit k of byte j.  c-blosc shuffles only blocks whose element count is a multiple
+// of 8 and copies every other block (and the blocksize % typesize tail) unchanged (shuffle.c: blosc_internal_bitshuffle).
+inline void blosc_unbitshuffle(size_t typesize, size_t blocksize, const unsigned char* src, unsigned char* dst) {
+  const size_t ne = blocksize / typesize;
+  if (ne == 0 || (ne & 7) != 0) { memcpy(dst, src, blocksize); return; }
+  const size_t row = ne / 8;
+  memset(dst, 0, ne * typesize);
+  for (size_t s = 0; s < typesize; ++s)
+    for (size_t b = 0; b < 8; ++b) {
+      const unsigned char* r = src + (s * 8 + b) * row;
+      for (size_t j = 0; j < row; ++j) {
+        const unsigned v = r[j];
+        if (!v) continue;
+        unsigned char* d = dst + (8 * j) * typesize + s;
+        for (size_t k = 0; k < 8; ++k) d[k * typesize] |= (unsigned char)(((v >> k) & 1u) << b);
+      }
+    }
+  memcpy(dst + ne * typesize, src + ne * typesize, blocksize - ne * typesize);
+}
+
+// blosclz (c-blosc's own LZ77 codec, a FastLZ descendant; format of blosclz.c 2.x as shipped with c-blosc 1.21):
+// a stream of instructions, each led by a control byte c (the first one is masked with 31):
+//   c < 32:  c + 1 literal bytes follow;
+//   c >= 32: a match of length (c >> 5) - 1 + 3 -- when the 3-bit field is 7, length bytes follow and add up until one
+//            is not 255 -- at distance ((c & 31) << 8) + next byte + 1; the pair (31, 255) announces a 16-bit far
+//            distance: two more bytes (big-endian) + 8191 + 1.  Matches may overlap their own output (runs).
+// Returns the number of bytes produced, 0 for a stream that does not decode inside its buffers.
+inline size_t blosclz_decompress(const unsigned char* in, size_t length, unsigned char* out, size_t maxout) {
+  if (length == 0) return 0;
+  const unsigned char* ip = in;
+  const unsigned char* const ip_end = in + length;
+  unsigned char* op = out;
+  unsigned char* const op_end = out + maxout;
+  unsigned ctrl = (*ip++) & 31u;
+  for (;;) {
+    if (ctrl >= 32u) {
+      size_t len = (ctrl >> 5) - 1;
+      size_t ofs = (size_t)(ctrl & 31u) << 8;
+      unsigned code;
+      if (len == 7 - 1) {
+        do {
+          if (ip + 1 >= ip_end) return 0;
+          code = *ip++;
+          len += code;
+        } while (code == 255);
+      } else if (ip + 1 >= ip_end) {
+        return 0;
+      }
+      code = *ip++;
+      len += 3;
+      size_t dist = ofs + code;
+      if (code == 255 && ofs == ((size_t)31 << 8)) {
+        if (ip + 1 >= ip_end) return 0;
+        dist = ((size_t)ip[0] << 8) + ip[1] + 8191;
+        ip += 2;
+      }
+      dist += 1;
+      if (len > (size_t)(op_end - op) || dist > (size_t)(op - out)) return 0;
+      const unsigned char* ref = op - dist;
+      for (size_t i = 0; i < len; ++i) op[i] = ref[i];  // byte by byte: overlapping matches replicate
+      op += len;
+      if (ip >= ip_end) break;  // a stream may end on a match
+      ctrl = *ip++;
+    } else {
+      const size_t run = ctrl + 1;
+      if (run > (size_t)(op_end - op) || run > (size_t)(ip_end - ip)) return 0;
+      memcpy(op, ip, run);
+      op += run;
+      ip += run;
+      if (ip >= ip_end) break;
+      ctrl = *ip++;
+    }
+  }
+  return (size_t)(op - out);
+}
+
 // One Blosc frame -> dst (exactly `want` bytes).  Returns "" or an error text.
 inline std::string blosc_decode(const unsigned char* src, size_t n, void* dst, size_t want) {
   if (n < (size_t)kBloscHeader) return "blosc: frame shorter than its header";
@@ -224,7 +305,6 @@ inline std::string blosc_decode(const unsigned char* src, size_t n, void* dst, s
     memcpy(dst, src + kBloscHeader, nbytes);
     return "";
   }
-  if (flags & kBloscBitshuffle) return "blosc: bit-shuffled frames are not supported";
   if (blocksize == 0 || blocksize > nbytes) return "blosc: bad block size";
   const size_t nblocks = (nbytes + blocksize - 1) / blocksize;
   if (kBloscHeader + 4 * nblocks > cbytes) return "blosc: truncated block table";
@@ -232,10 +312,13 @@ inline std::string blosc_decode(const unsigned char* src, size_t n, void* dst, s
   const InnerCodecs& lib = inner_codecs();
   if (inner == kInnerZstd && !zstd_available()) return "blosc: libzstd.so.1 is not available";
   if (inner == kInnerLz4 && !lib.lz4_decompress_safe) return "blosc: liblz4.so.1 is not available";
-  if (inner == kInnerBlosclz || inner == kInnerSnappy || inner > kInnerZstd)
-    return std::string("blosc: inner codec ") + (inner == kInnerBlosclz ? "blosclz" : inner == kInnerSnappy ? "snappy" : "?") +
-           " is not supported (zstd, lz4, zlib are)";
-  const bool shuffle = (flags & kBloscShuffle) && typesize > 1;
+  if (inner == kInnerSnappy || inner > kInnerZstd)
+    return std::string("blosc: inner codec ") + (inner == kInnerSnappy ? "snappy" : "?") +
+           " is not supported (zstd, lz4 / lz4hc, blosclz, zlib are)";
+  // (blosc.c: the byte shuffle is skipped for typesize 1, the bit shuffle is not; a block shorter than one element is
+  //  left alone by both)
+  const bool bitshuffle = (flags & kBloscBitshuffle) != 0;
+  const bool shuffle = bitshuffle || ((flags & kBloscShuffle) && typesize > 1);
   const bool dont_split = (flags & kBloscDontSplit) != 0;
   std::vector<unsigned char> tmp(shuffle ? blocksize : 0);
   for (size_t b = 0; b < nblocks; ++b) {
@@ -259,6 +342,8 @@ inline std::string blosc_decode(const unsigned char* src, size_t n, void* dst, s
       } else if (inner == kInnerLz4) {
         if (lib.lz4_decompress_safe((const char*)src + pos, (char*)out, (int)cs, (int)neblock) != (int)neblock)
           return "blosc: bad lz4 stream";
+      } else if (inner == kInnerBlosclz) {
+        if (blosclz_decompress(src + pos, cs, out, neblock) != neblock) return "blosc: bad blosclz stream";
       } else {
         uLongf got = (uLongf)neblock;
         if (uncompress(out, &got, src + pos, (uLong)cs) != Z_OK || got != neblock) return "blosc: bad zlib stream";
@@ -266,7 +351,12 @@ inline std::string blosc_decode(const unsigned char* src, size_t n, void* dst, s
       pos += cs;
       out += neblock;
     }
-    if (shuffle) blosc_unshuffle(typesize, bsize, tmp.data(), (unsigned char*)dst + b * blocksize);
+    if (bitshuffle) {
+      if (bsize >= typesize) blosc_unbitshuffle(typesize, bsize, tmp.data(), (unsigned char*)dst + b * blocksize);
+      else memcpy((unsigned char*)dst + b * blocksize, tmp.data(), bsize);
+    } else if (shuffle) {
+      blosc_unshuffle(typesize, bsize, tmp.data(), (unsigned char*)dst + b * blocksize);
+    }
   }
   return "";
 }

@@ -6,8 +6,9 @@ implementation of the subset it needs: C-order arrays, little-endian numeric dty
 production arrays are ``uint16``, chunks ``(1, 1, 64, 128, 128)``, ``Blosc(cname="zstd", clevel=3, shuffle=SHUFFLE)``,
 ``dimension_separator="/"`` (``zarr_destriper.py:1066-1074``).  Blosc frames are decoded / encoded by the native
 library (``csrc/dsx_io.h``: the c-blosc 1.x container restated from its format description, ``libzstd.so.1`` /
-``liblz4.so.1`` of the image ``dlopen``ed; frames with zstd, lz4 or zlib inside are read, zstd frames are written).
-Parity of that codec is UNPINNED: no file written by the real library exists here to check against.
+``liblz4.so.1`` of the image ``dlopen``ed; frames with zstd, lz4, blosclz or zlib inside, byte- or bit-shuffled, are
+read -- Zarr's own default ``Blosc(lz4, 5, SHUFFLE)`` included -- and zstd frames are written).  Pinned by frames of the
+real c-blosc 1.21.0 (``tests/golden/blosc_frames.npz``, ``oracle/make_golden_blosc.py``).
 """
 
 import itertools

@@ -181,8 +181,9 @@ int dsx_downsample2_u16(dsx_ctx* ctx, const void* d_src, void* d_dst, int Z, int
  * `threads` native threads -- what zarr / numcodecs do under the reference's worker processes
  * (zarr_destriper.py:336, 1042-1074).  codec: raw chunks, zlib streams, or Blosc frames -- the production
  * arrays are Blosc(cname="zstd", clevel=3, shuffle=SHUFFLE) (zarr_destriper.py:1066-1074); the c-blosc 1.x
- * container is restated in csrc/dsx_io.h (zstd / lz4 / zlib inside, byte shuffle; libzstd.so.1 is dlopen'ed),
- * parity unpinned: no file of the real library is available to check against.  A missing chunk reads as the
+ * container is restated in csrc/dsx_io.h (zstd / lz4 / blosclz / zlib inside, byte or bit shuffle; libzstd.so.1
+ * and liblz4.so.1 are dlopen'ed), pinned by frames of the real c-blosc 1.21.0 (tests/golden/blosc_frames.npz) and by
+ * decoding this writer's frames with that library (tests/test_blosc.py).  A missing chunk reads as the
  * 16-bit fill value; writes go to "<path>.tmp" and are renamed.  bytes[i] is the decompressed chunk size.
  * Synchronous; no GPU involved (ctx may be NULL: the message of a failure is then read with
  * dsx_last_error(NULL)).                                                                              */

@@ -29,6 +29,29 @@ int main(int argc, char** argv) {
     if (r.empty()) ++oks; else ++errs;
   }
   printf("mutations: %d rejected, %d decoded\n", errs, oks);
+  // the same frames read as blosclz streams (inner codec 0), half of them with the bit-shuffle flag: the zstd bytes are
+  // then a random blosclz instruction stream -- literal runs, near / far matches, overlong lengths, truncations
+  int lz_errs = 0, lz_oks = 0;
+  for (int it = 0; it < iters / 2; ++it) {
+    std::vector<unsigned char> f = frame;
+    f[2] = (unsigned char)((f[2] & 0x1F) | ((rng() & 1) ? 0x4 : 0x0));
+    if (rng() % 4 == 0) f[3] = (unsigned char)(1 + rng() % 9);  // type size (split count, bit rows)
+    int k = rng() % 4;
+    for (int j = 0; j < k; ++j) f[16 + rng() % (f.size() - 16)] = (unsigned char)rng();
+    if (rng() % 5 == 0) f.resize(16 + rng() % (f.size() - 16));
+    std::string r = dsx::blosc_decode(f.data(), f.size(), out.data(), n);
+    if (r.empty()) ++lz_oks; else ++lz_errs;
+  }
+  // and the stream decoder alone: random instruction streams into buffers of random size
+  std::vector<unsigned char> lz(600), lzout(5000);
+  for (int it = 0; it < iters; ++it) {
+    const size_t len = rng() % lz.size(), cap = rng() % lzout.size();
+    for (size_t i = 0; i < len; ++i) lz[i] = (rng() % 3 == 0) ? (unsigned char)(0xE0 | (rng() & 31)) : (unsigned char)rng();
+    std::vector<unsigned char> in(lz.begin(), lz.begin() + len), o(cap);  // exact-size buffers: ASan sees one byte too many
+    const size_t got = dsx::blosclz_decompress(in.data(), len, o.data(), cap);
+    if (got > cap) { printf("blosclz produced more than its buffer\n"); return 1; }
+  }
+  printf("blosclz mutations: %d rejected, %d decoded\n", lz_errs, lz_oks);
   // png unfilter with random filter bytes
   std::vector<unsigned char> rows(100 * 301);
   for (int it = 0; it < 2000; ++it) {

@@ -1,10 +1,14 @@
 """Blosc chunks (the production codec: ``Blosc(cname="zstd", clevel=3, shuffle=SHUFFLE)``, reference
 ``zarr_destriper.py:1066-1074``) through the native container code of ``csrc/dsx_io.h``.
 
-PARITY UNPINNED: neither c-blosc / numcodecs nor any file they wrote is available here.  What stands in: a second,
-independent reading of the published c-blosc 1.x frame format, written in pure Python below (``py_blosc_*``; inner streams
-through Python's ``zlib`` and, via ctypes, the image's ``libzstd.so.1``).  Frames assembled by the Python writer -- with
-split blocks, leftover blocks, stored streams and zlib inside, none of which the native writer emits -- must decode
+PARITY PINNED (round 3): the image carries the real c-blosc 1.21.0 (``/opt/conda/lib/libblosc.so.1``, the library
+numcodecs.Blosc wraps; numcodecs itself is absent).  ``oracle/make_golden_blosc.py`` wrote ``tests/golden/blosc_frames.npz``
+with it -- 77 frames: blosclz / lz4 / lz4hc / zlib / zstd inside, no / byte / bit shuffle, type sizes 1 ... 8, split and
+unsplit blocks, short last blocks, stored frames -- which the native reader must decode to the seeded payloads; and where
+the library is present (this container, the GPU box) the native writer's frames are decoded by the real
+``blosc_decompress_ctx``.  Besides: a second, independent reading of the published c-blosc 1.x frame format in pure Python
+below (``py_blosc_*``; inner streams through Python's ``zlib`` and, via ctypes, the image's ``libzstd.so.1``).  Frames
+assembled by the Python writer -- with split blocks, leftover blocks, stored streams and zlib inside -- must decode
 natively, and frames of the native writer must decode with the Python reader.  All host code: no GPU needed.
 """
 
@@ -169,6 +173,82 @@ def test_frames_assembled_from_the_format_description_decode_natively(codec, spl
     assert mini_zarr.blosc_decode(frame, len(mixed)) == mixed
 
 
+def payload(kind, seed, nbytes):
+    """The payloads of oracle/make_golden_blosc.py, regenerated from their seeds."""
+    rs = np.random.RandomState(seed)
+    if kind == "brick":
+        n = nbytes // 2
+        b = ((np.arange(n) % 977) * 13 + rs.randint(0, 40, n) + 300).astype("<u2").tobytes()
+    elif kind == "noise":
+        b = rs.bytes(nbytes)
+    elif kind == "runs":
+        b = np.repeat(rs.randint(0, 256, nbytes // 37 + 1).astype(np.uint8), 37).tobytes()
+    elif kind == "f32":
+        b = np.cumsum(rs.standard_normal(nbytes // 4 + 1).astype(np.float32)).astype("<f4").tobytes()
+    else:
+        raise ValueError(kind)
+    return (b + bytes(nbytes))[:nbytes]
+
+
+def test_frames_written_by_the_real_c_blosc_decode_natively():
+    """tests/golden/blosc_frames.npz (c-blosc 1.21.0, oracle/make_golden_blosc.py): every inner codec, shuffle mode,
+    split layout and type size it produced; the stored / split / bit-shuffled / blosclz paths must all have been seen."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "blosc_frames.npz"))
+    assert str(g["blosc_version"]) == "1.21.0"
+    seen = set()
+    n = 0
+    while "frame_%03d" % n in g.files:
+        frame = g["frame_%03d" % n].tobytes()
+        cname, clevel, shuffle, typesize, kind, seed, nbytes, blocksize = str(g["case_%03d" % n]).split()
+        raw = payload(kind, int(seed), int(nbytes))
+        assert mini_zarr.blosc_decode(frame, len(raw)) == raw, str(g["case_%03d" % n])
+        flags = frame[2]
+        seen.add((flags >> 5, "stored" if flags & MEMCPYED else "bit" if flags & 0x4 else "byte" if flags & SHUFFLE else "plain",
+                  bool(flags & DONT_SPLIT)))
+        n += 1
+    assert n == 77
+    assert {c for c, _, _ in seen} == {0, 1, 3, 4}                       # blosclz, lz4 (+ lz4hc), zlib, zstd
+    assert {m for _, m, _ in seen} == {"stored", "bit", "byte", "plain"}
+    assert {d for _, _, d in seen} == {False, True}                      # split and unsplit block streams
+
+
+REAL_BLOSC = "/opt/conda/lib/libblosc.so.1"
+
+
+@pytest.mark.skipif(not os.path.exists(REAL_BLOSC), reason="the image's c-blosc is not here")
+def test_native_writer_frames_decode_with_the_real_c_blosc():
+    """What the chunk writer stores must be readable by the library the reference (numcodecs) reads with -- and what
+    that library writes for the production settings by this reader, on a whole production-size chunk."""
+    lib = ctypes.CDLL(REAL_BLOSC)
+    lib.blosc_decompress_ctx.restype = ctypes.c_int
+    lib.blosc_decompress_ctx.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    lib.blosc_cbuffer_validate.restype = ctypes.c_int
+    lib.blosc_cbuffer_validate.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    lib.blosc_compress_ctx.restype = ctypes.c_int
+    lib.blosc_compress_ctx.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p,
+                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    cases = [(_brick(7, (64, 128, 128)).tobytes(), 2, 3, True)]          # the production chunk (1, 1, 64, 128, 128) uint16
+    cases += [(payload("brick", 20, n), 2, 3, True) for n in (0, 1, 2, 127, 128, 129, 256 * 1024, 256 * 1024 + 2, 600001)]
+    cases += [(payload("f32", 21, 300000), 4, 9, True), (payload("runs", 22, 70001), 1, 5, True),
+              (payload("runs", 23, 70001), 8, 1, False), (payload("noise", 24, 50000), 2, 3, True),
+              (payload("brick", 25, 50000), 2, 0, True)]
+    for raw, typesize, clevel, shuffle in cases:
+        frame = mini_zarr.blosc_encode(raw, typesize, clevel=clevel, shuffle=shuffle)
+        nb = ctypes.c_size_t(0)
+        assert lib.blosc_cbuffer_validate(frame, len(frame), ctypes.byref(nb)) == 0 and nb.value == len(raw)
+        back = ctypes.create_string_buffer(max(len(raw), 1))
+        assert lib.blosc_decompress_ctx(frame, back, len(raw), 1) == len(raw), (len(raw), typesize, clevel, shuffle)
+        assert back.raw[: len(raw)] == raw
+    # the other direction at production size and settings: Blosc(cname="zstd", clevel=3, shuffle=SHUFFLE)
+    raw = cases[0][0]
+    buf = ctypes.create_string_buffer(len(raw) + 16)
+    n = lib.blosc_compress_ctx(3, 1, 2, len(raw), raw, buf, len(raw) + 16, b"zstd", 0, 1)
+    assert n > 0 and mini_zarr.blosc_decode(buf.raw[:n], len(raw)) == raw
+    # (and the sizes agree to a few percent: same inner codec and level, other block size)
+    ours = len(mini_zarr.blosc_encode(raw, 2, clevel=3, shuffle=True))
+    assert abs(ours - n) <= 0.05 * n, (ours, n)
+
+
 def test_malformed_frames_fail_loudly():
     raw = _brick(4, (4, 64, 64)).tobytes()
     good = mini_zarr.blosc_encode(raw, 2)
@@ -178,7 +258,7 @@ def test_malformed_frames_fail_loudly():
         (good, "chunk needs"),  # decoded into a chunk of another size
         (bytes([9]) + good[1:], "format version"),
         (good[:2] + bytes([good[2] & 0x1F]) + good[3:], "blosclz"),  # inner codec 0
-        (good[:2] + bytes([good[2] | 0x4]) + good[3:], "bit-shuffled"),
+        (good[:2] + bytes([(good[2] & 0x1F) | (2 << 5)]) + good[3:], "snappy"),  # (c-blosc 1.21 is built without it too)
         (good[:16] + struct.pack("<i", len(good) + 100) + good[20:], "outside the frame"),
         (good[:8] + struct.pack("<I", 0) + good[12:], "block size"),
     ):
@@ -238,6 +318,25 @@ def test_blosc_store_roundtrip_metadata_and_native_chunk_io(tmp_path):
     np.testing.assert_array_equal(MiniZarrArray.open(str(tmp_path / "d.zarr"))[...], data)
     with pytest.raises(NotImplementedError, match="read-only"):
         d[...] = data
+    # Zarr's own default codec -- Blosc(cname="lz4", clevel=5, shuffle=SHUFFLE) -- and a blosclz / bit-shuffle store, with
+    # chunk files written by the real c-blosc (golden frames 76 and 6: 8 x 64 x 64 and 8 000 uint16), through both readers
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "blosc_frames.npz"))
+    for k, cname, shuffle, shape in ((76, "lz4", 1, (8, 64, 64)), (6, "blosclz", 2, (8000,))):
+        case = str(g["case_%03d" % k]).split()
+        assert (case[0], int(case[2])) == (cname, shuffle)
+        want = np.frombuffer(payload(case[4], int(case[5]), int(case[6])), "<u2").reshape(shape)
+        e = MiniZarrArray.create(str(tmp_path / "e{}.zarr".format(k)), shape, shape, np.uint16,
+                                 compressor={"id": "blosc", "cname": cname, "clevel": 5, "shuffle": shuffle, "blocksize": 0})
+        idx = (0,) * len(shape)
+        os.makedirs(os.path.dirname(e._chunk_path(idx)), exist_ok=True)
+        open(e._chunk_path(idx), "wb").write(g["frame_%03d" % k].tobytes())
+        np.testing.assert_array_equal(MiniZarrArray.open(e.path)[...], want)
+        got1 = np.empty(shape, np.uint16)
+        cp = (ctypes.c_char_p * 1)(os.fsencode(e._chunk_path(idx)))
+        dp = (ctypes.c_void_p * 1)(got1.ctypes.data)
+        nb = (ctypes.c_size_t * 1)(got1.nbytes)
+        assert lib.dsx_io_read_chunks(None, cp, dp, nb, 1, 1, 2, 0) == 0
+        np.testing.assert_array_equal(got1, want)
 
 
 @pytest.mark.gpu

@@ -30,6 +30,9 @@ def run(cases=40, seed=2026, eng=None, any_wavelet=False):
         if rng.random() < 0.6: w = (w + 3) & ~3          # fused kernels need a multiple of 4
         if rng.random() < 0.3: w = (w + 7) & ~7          # lane-pair I/O of the final kernel: multiple of 8
         h = int(rng.integers(40, 700))
+        if not any_wavelet and rng.random() < 0.03:      # rows longer than one wave holds (k_rowfilter_wide), few rows
+            w = int(rng.choice([2304, 4606, 4608, 5120, 6001, 7000, 9216])) + int(rng.integers(0, 3))
+            h = int(rng.integers(12, 90))
         name = "db3"
         if any_wavelet:
             # (dmey is refused; rbio3.1 amplifies float32 round-off beyond 1e-4 at depth -- the reference's own float32
