@@ -174,6 +174,9 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef DSX_FWD_SPLIT
+#define DSX_FWD_SPLIT 1
+#endif
 #ifndef DSX_DPP_X
 #define DSX_DPP_X 1
 #endif
@@ -775,7 +778,11 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
         nxt[d][r] = march_issue<IN_KIND, FAST>(ms, a.ldin, a.H, 2 * (i_begin + 3 * d) + r, col);
     }
   }
-  for (int i = i_begin; i < i_end; i += 3) {
+  // One group of three output rows.  The steady groups run in a loop of their own (DSX_FWD_SPLIT): with both kinds of
+  // group in one loop body the two paths merge every iteration, and the compiler reconciles their register assignments
+  // with ~70 copies per group (the window, the prefetched rows, the level-2 state) -- a sixth of the loop's vector work.
+  auto group = [&](auto steady_c, int i) {
+    constexpr bool STEADY = decltype(steady_c)::value;
     MarchRaw cur[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) cur[r] = nxt[0][r];
@@ -792,7 +799,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
           nxt[DEPTH - 1][r] = march_issue<IN_KIND, FAST>(ms, a.ldin, a.H, 2 * (i + 3 * DEPTH) + r, col);
       }
     }
-    if (FUSE && DSX_FWD_STEADY && (EDGE ? (DSX_FWD_STEADY & 2) != 0 : true) && i >= steady_lo && i + 3 <= steady_hi) {  // wave-uniform
+    if (STEADY) {
       step(std::true_type(), i, cur[0], cur[1], win[0], win[1], win[2], win[3], win[4], win[5]);
       step(std::true_type(), i + 1, cur[2], cur[3], win[2], win[3], win[4], win[5], win[0], win[1]);
       step(std::true_type(), i + 2, cur[4], cur[5], win[4], win[5], win[0], win[1], win[2], win[3]);
@@ -801,7 +808,32 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
       if (i + 1 < i_end) step(std::false_type(), i + 1, cur[2], cur[3], win[2], win[3], win[4], win[5], win[0], win[1]);
       if (i + 2 < i_end) step(std::false_type(), i + 2, cur[4], cur[5], win[4], win[5], win[0], win[1], win[2], win[3]);
     }
+  };
+  const bool steady_on = FUSE && DSX_FWD_STEADY && (EDGE ? (DSX_FWD_STEADY & 2) != 0 : true);
+#if DSX_FWD_SPLIT
+  {
+    // groups start at i_begin + 3 g; the steady ones are those with steady_lo <= i and i + 3 <= steady_hi: a run
+    int i = i_begin;
+    int run_lo = i_end, run_hi = i_end;  // first steady group, first group after the run
+    if (steady_on) {
+      run_lo = i_begin + 3 * ((max(steady_lo - i_begin, 0) + 2) / 3);
+      run_hi = (steady_hi - run_lo >= 3) ? run_lo + 3 * ((steady_hi - run_lo) / 3) : run_lo;
+      if (run_hi == run_lo) run_lo = run_hi = i_end;
+    }
+#pragma nounroll
+    for (int part = 0; part < 2; ++part) {  // one copy of the general group serves the rows above and below the run
+      const int stop = part == 0 ? min(run_lo, i_end) : i_end;
+      for (; i < stop; i += 3) group(std::false_type(), i);
+      if (part == 0)
+        for (; i < run_hi; i += 3) group(std::true_type(), i);
+    }
   }
+#else
+  for (int i = i_begin; i < i_end; i += 3) {
+    if (steady_on && i >= steady_lo && i + 3 <= steady_hi) group(std::true_type(), i);  // wave-uniform
+    else group(std::false_type(), i);
+  }
+#endif
 
   qmin = wave_min_f32(qmin);
   qmax = wave_max_f32(qmax);
