@@ -168,12 +168,20 @@ __device__ __forceinline__ float wave_min_no_nan(float v) {
 // Compiler-level + wavefront-scope ordering of LDS traffic inside ONE wave (no s_barrier):
 // the hardware executes a wave's LDS instructions in order; this keeps the compiler from
 // forwarding or reordering accesses across the point where other lanes' data is exchanged.
+// value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ unsigned swap_adjacent(unsigned v) {
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef DSX_FWD_PAIR
+#define DSX_FWD_PAIR 1  // interior strips of the fused uint16 forward kernel load pixel rows by lane pairs (16 bytes per lane)
+#endif
 #ifndef DSX_FWD_SPLIT
 #define DSX_FWD_SPLIT 1
 #endif
@@ -502,6 +510,32 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   else if (IN_KIND == 1) src = (const float*)a.in + plane * a.in_plane_stride;
   else src = a.ws + plane * a.ws_plane_stride + a.in_off;
   const MarchSrc<IN_KIND> ms(src, col);
+  // PAIRLD (interior strips of the fused uint16 kernel): pixel rows are read by lane PAIRS -- the even lane loads 16 bytes
+  // (the pair's 8 columns) of raw row g, the odd lane those of row g + 1, and the halves are exchanged over the DPP
+  // crossbar when the group is consumed: half as many load instructions, and 16-byte accesses (8-byte ones top out at
+  // 3.9 TB/s on this chip, which is where this kernel ran alone; tools/bw_access_width.py, inv_march_body<.., PAIR>)
+  constexpr bool PAIRLD = DSX_FWD_PAIR && FUSE && FAST && !EDGE && IN_KIND == 0;
+  const bool odd_lane = (lane & 1) != 0;
+  const unsigned pitch_b = (unsigned)a.ldin * 2u;
+  const unsigned voff_pair0 = (unsigned)(col.base - (odd_lane ? 4 : 0)) * 2u;   // the pair's first column (interior: >= 0)
+  const unsigned voff_pair = voff_pair0 + (odd_lane ? pitch_b : 0u);
+  auto issue_pairs = [&](int g0, MarchRaw (&out)[6]) {  // raw rows g0 .. g0 + 5 as three pair loads -> out[0], out[2], out[4]
+    if (g0 >= 0 && g0 + 5 < a.H) {  // wave-uniform
+      unsigned soff = (unsigned)g0 * pitch_b;
+#pragma unroll
+      for (int p = 0; p < 3; ++p, soff += 2u * pitch_b) {
+        const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(ms.rs, voff_pair, soff, 0);
+        out[2 * p].f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+      }
+    } else {  // first / last groups of a plane: reflected rows, one row offset per lane
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const int re = reflect_idx(g0 + 2 * p, a.H), ro = reflect_idx(g0 + 2 * p + 1, a.H);
+        const dsx_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(ms.rs, voff_pair0 + (unsigned)(odd_lane ? ro : re) * pitch_b, 0u, 0);
+        out[2 * p].f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+      }
+    }
+  };
   float* aa = a.ws + plane * a.ws_plane_stride + a.aa_off;
   float* da = a.ws + plane * a.ws_plane_stride + a.da_off;
   // fused kernel: coefficient rows are stored through buffer descriptors (row offset in an SGPR)
@@ -770,7 +804,9 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   MarchRaw nxt[DEPTH][6];
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) {
-    if (FAST) {
+    if (PAIRLD) {
+      issue_pairs(2 * (i_begin + 3 * d), nxt[d]);
+    } else if (FAST) {
       march_issue6<IN_KIND>(ms, a.ldin, a.H, 2 * (i_begin + 3 * d), col, nxt[d]);
     } else {
 #pragma unroll
@@ -786,12 +822,28 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     MarchRaw cur[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) cur[r] = nxt[0][r];
+    if (PAIRLD) {
+      // pair p: this lane's 16 bytes of row 2p + (lane & 1); the own half of the own row stays, the other row's own half
+      // comes from the neighbour
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const unsigned x = __float_as_uint(nxt[0][2 * p].f.x), y = __float_as_uint(nxt[0][2 * p].f.y);
+        const unsigned z = __float_as_uint(nxt[0][2 * p].f.z), w = __float_as_uint(nxt[0][2 * p].f.w);
+        const unsigned gx = swap_adjacent(odd_lane ? x : z), gy = swap_adjacent(odd_lane ? y : w);
+        cur[2 * p].f.x = __uint_as_float(odd_lane ? gx : x);      // row 2p, own 4 columns
+        cur[2 * p].f.y = __uint_as_float(odd_lane ? gy : y);
+        cur[2 * p + 1].f.x = __uint_as_float(odd_lane ? z : gx);  // row 2p + 1
+        cur[2 * p + 1].f.y = __uint_as_float(odd_lane ? w : gy);
+      }
+    }
 #pragma unroll
     for (int d = 0; d + 1 < DEPTH; ++d)
 #pragma unroll
       for (int r = 0; r < 6; ++r) nxt[d][r] = nxt[d + 1][r];
     if (i + 3 * DEPTH < i_end) {
-      if (FAST) {
+      if (PAIRLD) {
+        issue_pairs(2 * (i + 3 * DEPTH), nxt[DEPTH - 1]);
+      } else if (FAST) {
         march_issue6<IN_KIND>(ms, a.ldin, a.H, 2 * (i + 3 * DEPTH), col, nxt[DEPTH - 1]);
       } else {
 #pragma unroll
@@ -2150,11 +2202,6 @@ __device__ __forceinline__ dsx_f2 pk_dot6(dsx_f2 a0, float t0, dsx_f2 a1, float 
   v = pk_fma(d1, u1, v);
   v = pk_fma(d2, u2, v);
   return v;
-}
-
-// value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
-__device__ __forceinline__ unsigned swap_adjacent(unsigned v) {
-  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
 }
 
 // Two results as packed uint16: v_cvt_u32_f32 saturates below at 0 (negative, NaN) and v_cvt_pk_u16_u32 above at 65535 --
