@@ -15,6 +15,12 @@
 #ifndef DSX_FFT_CORE_H
 #define DSX_FFT_CORE_H
 
+#ifndef DSX_SCALAR_FMA
+#define DSX_SCALAR_FMA 1  // the multiply-adds of pk_fma / the complex helpers as scalar v_fma_f32 (see __graft_entry__.build)
+#endif
+#ifndef DSX_SCALAR_CMUL
+#define DSX_SCALAR_CMUL DSX_SCALAR_FMA
+#endif
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define DSX_HD __host__ __device__ __forceinline__
@@ -29,7 +35,7 @@ DSX_HD dsx_c32 dsx_sub(dsx_c32 a, dsx_c32 b) { return a - b; }
 DSX_HD dsx_c32 dsx_mul_mi(dsx_c32 a) { return dsx_c32{a.y, -a.x}; }
 // (a - b) * (-i) = (a.y - b.y, b.x - a.x) in one packed add (half selection and signs on the operands)
 DSX_HD dsx_c32 dsx_sub_mi(dsx_c32 a, dsx_c32 b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DSX_NO_ASM_CMUL)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DSX_NO_ASM_CMUL) && !DSX_SCALAR_FMA
   dsx_c32 d;
   asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
   return d;
@@ -41,7 +47,11 @@ DSX_HD dsx_c32 dsx_sub_mi(dsx_c32 a, dsx_c32 b) {
 // operands, where the compiler builds {-b.y, b.x} with a v_xor and a v_mov first
 //   t = (-a.y b.y, a.y b.x);   d = (a.x b.x + t.lo, a.x b.y + t.hi)
 DSX_HD dsx_c32 dsx_mul(dsx_c32 a, dsx_c32 b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DSX_NO_ASM_CMUL)
+#if defined(__HIP_DEVICE_COMPILE__) && DSX_SCALAR_CMUL
+  // the same four roundings as the packed pair below, as two multiplies and two multiply-adds
+  const float tx = -(a.y * b.y), ty = a.y * b.x;
+  return dsx_c32{__builtin_fmaf(a.x, b.x, tx), __builtin_fmaf(a.x, b.y, ty)};
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(DSX_NO_ASM_CMUL)
   dsx_c32 t, d;
   asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "v"(b));
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
@@ -52,7 +62,11 @@ DSX_HD dsx_c32 dsx_mul(dsx_c32 a, dsx_c32 b) {
 }
 DSX_HD dsx_c32 dsx_scale(dsx_c32 a, float s) { return a * s; }
 // a * s + b
+#if DSX_SCALAR_FMA
+DSX_HD dsx_c32 dsx_fma_s(dsx_c32 a, float s, dsx_c32 b) { return dsx_c32{__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y)}; }
+#else
 DSX_HD dsx_c32 dsx_fma_s(dsx_c32 a, float s, dsx_c32 b) { return a * s + b; }
+#endif
 #else
 #define DSX_HD inline
 struct dsx_c32 {

@@ -93,6 +93,11 @@ constexpr int kBufNT = 2;  // aux bits of a streaming (non-temporal) buffer acce
 // the choice of which product is rounded first to the compiler, and two inlined copies of one expression --
 // a segment's prologue and its steady-state loop -- did pick differently: results then depended on where
 // the row segments of a launch start, i.e. on the batch size.)
+#if DSX_SCALAR_FMA
+__device__ __forceinline__ dsx_f2 pk_fma(dsx_f2 a, dsx_f2 b, dsx_f2 c) { return dsx_f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+__device__ __forceinline__ dsx_f2 pk_fma(dsx_f2 a, float b, dsx_f2 c) { return dsx_f2{fmaf(a.x, b, c.x), fmaf(a.y, b, c.y)}; }
+__device__ __forceinline__ dsx_f2 pk_fma(float a, dsx_f2 b, dsx_f2 c) { return dsx_f2{fmaf(a, b.x, c.x), fmaf(a, b.y, c.y)}; }
+#else
 __device__ __forceinline__ dsx_f2 pk_fma(dsx_f2 a, dsx_f2 b, dsx_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ dsx_f2 pk_fma(dsx_f2 a, float b, dsx_f2 c) {
   const dsx_f2 bb = {b, b};
@@ -102,6 +107,7 @@ __device__ __forceinline__ dsx_f2 pk_fma(float a, dsx_f2 b, dsx_f2 c) {
   const dsx_f2 aa = {a, a};
   return __builtin_elementwise_fma(aa, b, c);
 }
+#endif
 
 struct PlaneStats {
   double sum_fg;               // sum of pixels in the foreground class (>= cut-off)
@@ -151,6 +157,11 @@ __device__ __forceinline__ float min_no_nan(float a, float b) {
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ float max_no_nan(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // Wave minimum of values that are never NaN; the result is wave-uniform.  Four DPP steps inside the rows of 16 lanes
 // (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: every lane then holds its row's minimum), then the four
 // rows through v_readlane -- no LDS crossbar (__shfl_xor is ds_bpermute_b32 + a wait per step).
@@ -179,6 +190,9 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef DSX_SCALAR_FMA
+#define DSX_SCALAR_FMA 1  // the multiply-adds of pk_fma / the complex helpers as scalar v_fma_f32 (see __graft_entry__.build)
+#endif
 #ifndef DSX_FWD_PAIR
 #define DSX_FWD_PAIR 1  // interior strips of the fused uint16 forward kernel load pixel rows by lane pairs (16 bytes per lane)
 #endif
@@ -619,8 +633,10 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
     wave_sync();
 #endif
     const float q = v.y * v.y;
-    q2min = fminf(q2min, l2_valid ? q : __builtin_huge_valf());
-    q2max = fmaxf(q2max, l2_valid ? q : 0.f);
+    // (running extrema as bare v_min / v_max: fminf / fmaxf quiet a possible signalling NaN of every operand first, one
+    //  more 5-cycle instruction each -- a NaN coefficient means a flagged plane, PlaneStats::flags)
+    q2min = min_no_nan(q2min, l2_valid ? q : __builtin_huge_valf());
+    q2max = max_no_nan(q2max, l2_valid ? q : 0.f);
     if (l2_store && !DSX_ABL(a, 16 | 128)) {  // 128: diagnosis, only the level-2 stores are left out
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), rs_aa2, off_2, (unsigned)(i2 * a.lda2) * 4u, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), rs_da2, off_2, (unsigned)(i2 * a.ld2) * 4u, 0);
@@ -728,8 +744,8 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
             if (c_s1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(res[1][1]), rs_da, off_da + 4u, soff, aux);
           }
         }
-        qmin = fminf(qmin, fminf(c_v0 ? q0 : __builtin_huge_valf(), c_v1 ? q1 : __builtin_huge_valf()));
-        qmax = fmaxf(qmax, fmaxf(c_v0 ? q0 : 0.f, c_v1 ? q1 : 0.f));
+        qmin = min_no_nan(qmin, min_no_nan(c_v0 ? q0 : __builtin_huge_valf(), c_v1 ? q1 : __builtin_huge_valf()));
+        qmax = max_no_nan(qmax, max_no_nan(c_v0 ? q0 : 0.f, c_v1 ? q1 : 0.f));
         // aa_1 row -> ring; edge strips also write the half-sample symmetric extension:
         // aa[-1-k] = aa[k] (k < 4), aa[w + k] = aa[w - 1 - k] (k < 6)
         float* ring = s_ring[wave][i & (kRingRows - 1)];
@@ -772,14 +788,14 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
         *(float2*)(aa + oa) = make_float2(res[0][0], res[0][1]);
         *(float2*)(da + o) = make_float2(res[1][0], res[1][1]);
         const float q0 = res[1][0] * res[1][0], q1 = res[1][1] * res[1][1];
-        qmin = fminf(qmin, fminf(q0, q1));
-        qmax = fmaxf(qmax, fmaxf(q0, q1));
+        qmin = min_no_nan(qmin, min_no_nan(q0, q1));
+        qmax = max_no_nan(qmax, max_no_nan(q0, q1));
       } else if (j < a.w) {
         aa[oa] = res[0][0];
         da[o] = res[1][0];
         const float q0 = res[1][0] * res[1][0];
-        qmin = fminf(qmin, q0);
-        qmax = fmaxf(qmax, q0);
+        qmin = min_no_nan(qmin, q0);
+        qmax = max_no_nan(qmax, q0);
       }
       // half-sample symmetric extension of aa into the row margins: aa[-1-k] = aa[k] (k < 4),
       // aa[w + k] = aa[w - 1 - k] (k < 8); read by the next level's aligned vector loads

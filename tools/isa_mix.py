@@ -4,7 +4,7 @@
 import collections, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 S = "/tmp/dsx_isa.s"
-subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-S", "-o", S,
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only", "-S", "-o", S,
                 "dsx.hip"] + [a for a in sys.argv[1:] if a.startswith("-D")], cwd=os.path.join(ROOT, "aind_smartspim_destripe_amd", "csrc"), check=True,
                stderr=subprocess.DEVNULL)
 want = [a for a in sys.argv[1:] if not a.startswith("-D")] or ["k_rowfinalILi18", "k_fwd_marchILi0ELb1ELi8", "k_rowfilterILi18ELi2ELi1ELi1ELi2", "k_hist"]
