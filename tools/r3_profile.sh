@@ -6,6 +6,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 T=${1:-r3}
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q -s > gpurun_out/${T}_gpu_tests.log 2>&1; echo "tests rc=$?" | tee -a gpurun_out/${T}_gpu_tests.log
+python tools/fuzz_parity.py 600 424242 > gpurun_out/${T}_fuzz_parity.log 2>&1; echo "fuzz rc=$?"; tail -1 gpurun_out/${T}_fuzz_parity.log
+python tools/fuzz_parity.py 300 98765 wavelets > gpurun_out/${T}_fuzz_wavelets.log 2>&1; echo "wavelet fuzz rc=$?"; tail -1 gpurun_out/${T}_fuzz_wavelets.log
 python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench_driver_style.json 2> gpurun_out/${T}_bench_driver_style.err; echo "driver-style bench rc=$?"
 python bench.py --steps 200 --warmup 20 --kernel-breakdown > gpurun_out/${T}_bench_2048.json 2> gpurun_out/${T}_bench_2048.err
 rm -rf gpurun_out/kstats
