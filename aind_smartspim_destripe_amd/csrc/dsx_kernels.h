@@ -184,6 +184,45 @@ __device__ __forceinline__ unsigned swap_adjacent(unsigned v) {
   return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
 }
 
+// Bit e of a slot mask as a select mask (all ones / zero: one v_bfe_i32) and the select itself as one v_bfi_b32.  Written
+// as "bit ? a : b" the compiler emits v_and + v_cmp + v_cndmask: 13.8 cycles of a SIMD per select against 6.2
+// (tools/micro/valu_rate.hip).
+template <typename M>
+__device__ __forceinline__ int slot_mask(M m, int e) {
+  const unsigned w = (sizeof(M) == 8 && e >= 32) ? (unsigned)((unsigned long long)m >> 32) : (unsigned)m;
+  return (int)(w << (31 - (e & 31))) >> 31;
+}
+// An opaque copy of a slot mask: the select masks of a later stage are then extracted again (one instruction each) instead
+// of being kept in registers across the transforms in between (36 of them).
+template <typename M>
+__device__ __forceinline__ M opaque_mask(M m) {
+  if constexpr (sizeof(M) == 8) {
+    unsigned lo = (unsigned)m, hi = (unsigned)((unsigned long long)m >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return (M)(((unsigned long long)hi << 32) | lo);
+  } else {
+    unsigned lo = (unsigned)m;
+    asm volatile("" : "+v"(lo));
+    return (M)lo;
+  }
+}
+// (as assembly: from the C expression the compiler keeps ~m in a register and emits v_and + v_and_or, or reads a uniform
+//  operand from an SGPR -- 6.2 / 5.5 cycles where this is 3.1)
+__device__ __forceinline__ unsigned bit_select(int m, unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+}
+// all ones on odd lanes, zero on even ones, opaque to the optimiser (see slot_mask): the lane-pair exchanges select with it
+__device__ __forceinline__ int odd_lane_mask(int lane) {
+  int m = -(lane & 1);
+  asm("" : "+v"(m));
+  return m;
+}
+__device__ __forceinline__ float bit_select(int m, float a, float b) {  // m ? a : b
+  return as_f32(bit_select(m, as_u32(a), as_u32(b)));
+}
+
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -530,6 +569,7 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   // 3.9 TB/s on this chip, which is where this kernel ran alone; tools/bw_access_width.py, inv_march_body<.., PAIR>)
   constexpr bool PAIRLD = DSX_FWD_PAIR && FUSE && FAST && !EDGE && IN_KIND == 0;
   const bool odd_lane = (lane & 1) != 0;
+  const int oddm = odd_lane_mask(lane);
   const unsigned pitch_b = (unsigned)a.ldin * 2u;
   const unsigned voff_pair0 = (unsigned)(col.base - (odd_lane ? 4 : 0)) * 2u;   // the pair's first column (interior: >= 0)
   const unsigned voff_pair = voff_pair0 + (odd_lane ? pitch_b : 0u);
@@ -845,11 +885,11 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
       for (int p = 0; p < 3; ++p) {
         const unsigned x = __float_as_uint(nxt[0][2 * p].f.x), y = __float_as_uint(nxt[0][2 * p].f.y);
         const unsigned z = __float_as_uint(nxt[0][2 * p].f.z), w = __float_as_uint(nxt[0][2 * p].f.w);
-        const unsigned gx = swap_adjacent(odd_lane ? x : z), gy = swap_adjacent(odd_lane ? y : w);
-        cur[2 * p].f.x = __uint_as_float(odd_lane ? gx : x);      // row 2p, own 4 columns
-        cur[2 * p].f.y = __uint_as_float(odd_lane ? gy : y);
-        cur[2 * p + 1].f.x = __uint_as_float(odd_lane ? z : gx);  // row 2p + 1
-        cur[2 * p + 1].f.y = __uint_as_float(odd_lane ? w : gy);
+        const unsigned gx = swap_adjacent(bit_select(oddm, x, z)), gy = swap_adjacent(bit_select(oddm, y, w));
+        cur[2 * p].f.x = __uint_as_float(bit_select(oddm, gx, x));      // row 2p, own 4 columns
+        cur[2 * p].f.y = __uint_as_float(bit_select(oddm, gy, y));
+        cur[2 * p + 1].f.x = __uint_as_float(bit_select(oddm, z, gx));  // row 2p + 1
+        cur[2 * p + 1].f.y = __uint_as_float(bit_select(oddm, w, gy));
       }
     }
 #pragma unroll
@@ -1758,8 +1798,8 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
   for_slots<GV>(gf, nt, [&](int e) {
     const int n = (e < 4 * GV) ? 256 * (e >> 2) + 4 * lane + (e & 3) : tn + 64 * (e - 4 * GV);
     if (e < 4 * GV || n < N) {
-      const float xa = ((maska >> e) & (mask_t)1) ? meda : va[e];
-      const float xb = ((maskb >> e) & (mask_t)1) ? medb : vb[e];
+      const float xa = bit_select(slot_mask(maska, e), meda, va[e]);
+      const float xb = bit_select(slot_mask(maskb, e), medb, vb[e]);
       const float2 z = make_float2(xa, xb);
       buf[K + n] = z;
       if (halo) {
@@ -1806,17 +1846,20 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
   }
 
   // ---- buf = swap(M * LP): row a <- .y, row b <- .x ; Delta = -(1 - mask) LP (filtering.py:215-217)
+  maska = opaque_mask(maska);
+  maskb = opaque_mask(maskb);
   if (TO_LDS) {
     // every value is read out of the interleaved buffer before the first planar value overwrites it
     float oa[E], ob[E];
+    const int no_b = has_b ? 0 : -1;  // odd row count: the partner row of the last pair is all zeros
     for_slots<GV>(gf, nt, [&](int e) {
       const int n = (e < 4 * GV) ? 256 * (e >> 2) + 4 * lane + (e & 3) : tn + 64 * (e - 4 * GV);
       oa[e] = 0.f;
       ob[e] = 0.f;
       if (e < 4 * GV || n < N) {
         const float2 y = buf[K + n];
-        oa[e] = ((maska >> e) & (mask_t)1) ? 0.f : -y.y * a.inv_M;
-        ob[e] = (!has_b || ((maskb >> e) & (mask_t)1)) ? 0.f : -y.x * a.inv_M;
+        oa[e] = bit_select(slot_mask(maska, e), 0.f, -y.y * a.inv_M);
+        ob[e] = bit_select(slot_mask(maskb, e) | no_b, 0.f, -y.x * a.inv_M);
       }
     });
     wave_sync();
@@ -1849,8 +1892,8 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
       for (int i = 0; i < 4; ++i) {
         const int e = 4 * g + i;
         const float2 y = buf[K + nb0 + i];
-        da_[i] = ((maska >> e) & (mask_t)1) ? 0.f : -y.y * a.inv_M;
-        db_[i] = ((maskb >> e) & (mask_t)1) ? 0.f : -y.x * a.inv_M;
+        da_[i] = bit_select(slot_mask(maska, e), 0.f, -y.y * a.inv_M);
+        db_[i] = bit_select(slot_mask(maskb, e), 0.f, -y.x * a.inv_M);
       }
 #if DSX_NT
       const dsx_f4 oa = {da_[0], da_[1], da_[2], da_[3]}, ob = {db_[0], db_[1], db_[2], db_[3]};
@@ -1868,8 +1911,8 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
     if (k < nt && n < N) {
       const int e = 4 * GV + k;
       const float2 y = buf[K + n];
-      rowa[n] = ((maska >> e) & (mask_t)1) ? 0.f : -y.y * a.inv_M;
-      if (has_b) rowb[n] = ((maskb >> e) & (mask_t)1) ? 0.f : -y.x * a.inv_M;
+      rowa[n] = bit_select(slot_mask(maska, e), 0.f, -y.y * a.inv_M);
+      if (has_b) rowb[n] = bit_select(slot_mask(maskb, e), 0.f, -y.x * a.inv_M);
     }
   }
 }
@@ -2392,6 +2435,7 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     return r;
   };
   const bool odd_lane = (lane & 1) != 0;
+  const int oddm = odd_lane_mask(lane);
   const int xb = min(kMarchCols * strip + 8 * (lane >> 1), a.W - 8);  // PAIR: first column of the lane pair (clamped)
   // PAIR lane offsets: the odd lane of a pair takes the row below (pixels) / stores the row below (results)
   const unsigned vo_pair0 = (unsigned)xb * 2u, vo_pair = vo_pair0 + (odd_lane ? (unsigned)a.W * 2u : 0u);
@@ -2557,22 +2601,22 @@ __device__ __forceinline__ void inv_march_body(const FinalArgs& a, int lane, int
     if (PAIR) {
       // ri0.q: this lane's 16 bytes of row 2p + (lane & 1); the own half of the own row stays, the other
       // row's own half comes from the neighbour
-      const unsigned sx = odd_lane ? ri0.q.x : ri0.q.z, sy = odd_lane ? ri0.q.y : ri0.q.w;  // what the neighbour needs
+      const unsigned sx = bit_select(oddm, ri0.q.x, ri0.q.z), sy = bit_select(oddm, ri0.q.y, ri0.q.w);  // what the neighbour needs
       const unsigned gx = swap_adjacent(sx), gyv = swap_adjacent(sy);
       FinalRawI<IN_KIND> r0 = ri0, r1 = ri0;
-      r0.u = odd_lane ? make_uint2(gx, gyv) : make_uint2(ri0.q.x, ri0.q.y);      // row 2p, own 4 columns
-      r1.u = odd_lane ? make_uint2(ri0.q.z, ri0.q.w) : make_uint2(gx, gyv);      // row 2p + 1
+      r0.u = make_uint2(bit_select(oddm, gx, ri0.q.x), bit_select(oddm, gyv, ri0.q.y));      // row 2p, own 4 columns
+      r1.u = make_uint2(bit_select(oddm, ri0.q.z, gx), bit_select(oddm, ri0.q.w, gyv));      // row 2p + 1
       if (a.out_dtype == 0 && !DSX_ABL(a, 32)) {
         unsigned pe[2], po[2];
         emit_row(2 * p, r0, even, &pe);
         emit_row(2 * p + 1, r1, odd, &po);
         // even lane stores row 2p: [own | neighbour's] even-row pack; odd lane row 2p + 1: [neighbour's | own]
-        const unsigned tx = swap_adjacent(odd_lane ? pe[0] : po[0]), ty = swap_adjacent(odd_lane ? pe[1] : po[1]);
+        const unsigned tx = swap_adjacent(bit_select(oddm, pe[0], po[0])), ty = swap_adjacent(bit_select(oddm, pe[1], po[1]));
         dsx_u32x4 o4;
-        o4.x = odd_lane ? tx : pe[0];
-        o4.y = odd_lane ? ty : pe[1];
-        o4.z = odd_lane ? po[0] : tx;
-        o4.w = odd_lane ? po[1] : ty;
+        o4.x = bit_select(oddm, tx, pe[0]);
+        o4.y = bit_select(oddm, ty, pe[1]);
+        o4.z = bit_select(oddm, po[0], tx);
+        o4.w = bit_select(oddm, po[1], ty);
         const int gyl = 2 * p + (odd_lane ? 1 : 0);
         if (gyl < a.hout && x0 < a.wout)
           __builtin_amdgcn_raw_buffer_store_b128(o4, rs_out, vo_pair_out, (unsigned)(2 * p * a.wout) * 2u, kBufNT);
@@ -2710,6 +2754,7 @@ __device__ __forceinline__ void rowfinal_synth(const FinalArgs& a, const float2*
   const int xl = min(x0, a.W - 4);  // lanes right of the plane: clamped (valid) addresses, results never stored
   const int ql = xl >> 1;           // first Delta_1 / c_1 column of the lane
   const bool odd_lane = (lane & 1) != 0;
+  const int oddm = odd_lane_mask(lane);
   const int xb = min(kMarchCols * strip + 8 * (lane >> 1), a.W - 8);  // first column of the lane pair (clamped)
   const __amdgpu_buffer_rsrc_t rs_img = dsx_rsrc((const char*)a.img + plane * a.img_plane_stride * 2);
   const __amdgpu_buffer_rsrc_t rs_out = dsx_rsrc((const char*)a.out + plane * a.out_plane_stride * 2);
@@ -2849,19 +2894,19 @@ __device__ __forceinline__ void rowfinal_synth(const FinalArgs& a, const float2*
     }
     // ri: this lane's 16 bytes of pixel row 2p + (lane & 1); the own half of the own row stays, the other row's
     // own half comes from the neighbour (see inv_march_body<.., PAIR>)
-    const unsigned sx = odd_lane ? ri.x : ri.z, sy = odd_lane ? ri.y : ri.w;
+    const unsigned sx = bit_select(oddm, ri.x, ri.z), sy = bit_select(oddm, ri.y, ri.w);
     const unsigned gx = swap_adjacent(sx), gyv = swap_adjacent(sy);
-    const uint2 r0 = odd_lane ? make_uint2(gx, gyv) : make_uint2(ri.x, ri.y);  // row 2p, own 4 columns
-    const uint2 r1 = odd_lane ? make_uint2(ri.z, ri.w) : make_uint2(gx, gyv);  // row 2p + 1
+    const uint2 r0 = make_uint2(bit_select(oddm, gx, ri.x), bit_select(oddm, gyv, ri.y));  // row 2p, own 4 columns
+    const uint2 r1 = make_uint2(bit_select(oddm, ri.z, gx), bit_select(oddm, ri.w, gyv));  // row 2p + 1
     unsigned pe[2], po[2];
     px_row(2 * p, r0, even, pe);
     px_row(2 * p + 1, r1, odd, po);
-    const unsigned tx = swap_adjacent(odd_lane ? pe[0] : po[0]), ty = swap_adjacent(odd_lane ? pe[1] : po[1]);
+    const unsigned tx = swap_adjacent(bit_select(oddm, pe[0], po[0])), ty = swap_adjacent(bit_select(oddm, pe[1], po[1]));
     dsx_u32x4 o4;
-    o4.x = odd_lane ? tx : pe[0];
-    o4.y = odd_lane ? ty : pe[1];
-    o4.z = odd_lane ? po[0] : tx;
-    o4.w = odd_lane ? po[1] : ty;
+    o4.x = bit_select(oddm, tx, pe[0]);
+    o4.y = bit_select(oddm, ty, pe[1]);
+    o4.z = bit_select(oddm, po[0], tx);
+    o4.w = bit_select(oddm, po[1], ty);
     const int gyl = 2 * p + (odd_lane ? 1 : 0);
     if (gyl < a.hout && x0 < a.wout)
       __builtin_amdgcn_raw_buffer_store_b128(o4, rs_out, vo_pair_out, (unsigned)(2 * p * a.wout) * 2u, kBufNT);
