@@ -46,6 +46,10 @@ __global__ __launch_bounds__(512) void kb(float* out, int piece, int ld, int row
   for (int r = r0; r < r1; ++r) {
     const unsigned soff = (unsigned)r * (unsigned)ld * 4u;
     v += 1u;
+    if (W == 1) {  // 64 floats per instruction: as many instructions as the piece needs
+      for (int cc = lane; cc < piece; cc += 64) __builtin_amdgcn_raw_buffer_store_b32(v, rs, cc * 4u, soff, 0);
+      continue;
+    }
     if (full) {
       if (W == 1) __builtin_amdgcn_raw_buffer_store_b32(v, rs, c * 4u, soff, 0);
       if (W == 2) { u32x2 t = {v, v}; __builtin_amdgcn_raw_buffer_store_b64(t, rs, c * 4u, soff, 0); }
