@@ -420,7 +420,7 @@ def main():
                 "fft_len": [info.fft_len[i] for i in range(info.levels)],
                 "planes_with_cells_config": n_cells,
                 "parallelism": "z-sharded x{}".format(world),
-                "rccl_ranks": world if (world > 1 and group.transport == "rccl") else 0,
+                "rccl_ranks": world if group.transport == "rccl" else 0,
                 "rank_transport": group.transport,
                 "ranks_share_gpus": shared_gpu,
                 "rccl_error": group.comm_error,

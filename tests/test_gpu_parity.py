@@ -864,3 +864,28 @@ def test_bench_self_launch_two_ranks_on_the_one_gpu():
     assert d["n_gpus"] == 2 and d["verified"] is True and d["scaling"] == "weak"
     assert d["config"]["ranks_share_gpus"] is True and d["config"]["rank_transport"] in ("host", "rccl")
     assert abs(d["value"] - 2 * 32 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-2 * d["value"]
+
+
+def test_bench_under_a_launcher_with_a_real_rccl_communicator():
+    """The driver's multi-GPU command is `torch.distributed.run ... bench.py --gpus N`: RANK / WORLD_SIZE in the
+    environment, one rank per GPU, the constants broadcast over RCCL through the C ABI (`dsx_comm_*`, librccl.so
+    dlopen'ed by the library).  This box has ONE GPU, so the rehearsal is a world of one rank with DSX_FORCE_COMM=1: the
+    real ncclGetUniqueId / ncclCommInitRank / ncclBroadcast / ncclAllReduce / ncclCommDestroy on the device, the file
+    rendezvous around them, and a verified bench line that says so."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("DSX_RDZV_DIR", "DSX_SHARE_GPU")}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", DSX_FORCE_COMM="1")
+    r = subprocess.run(
+        [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "32",
+         "--settle", "0", "--shape", "512x512", "--cpu-planes", "0"],
+        capture_output=True, text=True, timeout=600, env=env)  # fmt: skip
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    c = d["config"]
+    assert d["n_gpus"] == 1 and d["verified"] is True
+    assert c["rank_transport"] == "rccl" and c["rccl_ranks"] == 1 and c["rccl_error"] is None, c
+    assert c["constants_broadcast_bytes"] > 0
