@@ -405,7 +405,12 @@ void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg,
   static const int target_waves = getenv("DSX_MARCH_WAVES") ? atoi(getenv("DSX_MARCH_WAVES")) : 256 * 16;
   static const bool no_quant = getenv("DSX_NO_QUANT") && atoi(getenv("DSX_NO_QUANT")) != 0;
   int want = (target_waves + nb * nstrips - 1) / (nb * nstrips);
-  const int max_seg = std::max(1, rows / 24);
+  // Rows per segment, at least: 24 until late in round 3.  The coarse levels (260 rows and fewer) then ran as a few
+  // hundred waves marching 24+ rows each -- launches that are short on parallelism, not on work: levels 3 ... 8 hold 6 % of
+  // the coefficients and cost 19 % of the run (timing-only DSX_SKIP_COARSE, profiles/r3_coarse_levels.txt).  4 rows per
+  // segment (2 more of halo) gives them 3-6 x the waves and a march a sixth as long: +1.5 % on the whole run.
+  static const int seg_min_rows = getenv("DSX_SEG_MIN_ROWS") ? std::max(2, atoi(getenv("DSX_SEG_MIN_ROWS"))) : 4;
+  const int max_seg = std::max(1, rows / seg_min_rows);
   want = std::max(1, std::min(want, max_seg));
   if (wpb > 0 && !no_quant) {
     static int cus = 0;
