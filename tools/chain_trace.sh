@@ -1,8 +1,8 @@
 #!/bin/bash
-# every kernel of one launch chain (single stream, 256 planes) in launch order with its duration
+# every kernel of one launch chain (single stream, 256 planes or CHAIN_BATCH) in launch order with its duration
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/ct
-DSX_STREAMS=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ct -- python3 bench.py --steps 1 --warmup 1 --cpu-planes 0 --settle 0 --no-verify > /dev/null 2>&1
+DSX_STREAMS=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ct -- python3 bench.py --steps 1 --warmup 1 --cpu-planes 0 --settle 0 --no-verify ${CHAIN_BATCH:+--batch $CHAIN_BATCH} > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob
 rows = []
