@@ -401,15 +401,19 @@ hipError_t launch_rowfilter_multi(const dsx::RowMultiArgs& a_in, const int* npai
 // the QUANTISATION of the launch -- blocks run in rounds of (CUs x 16 / wpb); 576 equal blocks on 512 slots take two
 // rounds, 512 take one.  Among the counts around the target the one with the smallest rounds x (rows per segment +
 // halo_rows) wins (halo_rows: the rows a segment recomputes, in the units of `rows`).
-void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg, int wpb = 0, int halo_rows = 0) {
+void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg, int wpb = 0, int halo_rows = 0,
+                    bool coarse = false) {
   static const int target_waves = getenv("DSX_MARCH_WAVES") ? atoi(getenv("DSX_MARCH_WAVES")) : 256 * 16;
   static const bool no_quant = getenv("DSX_NO_QUANT") && atoi(getenv("DSX_NO_QUANT")) != 0;
   int want = (target_waves + nb * nstrips - 1) / (nb * nstrips);
   // Rows per segment, at least: 24 until late in round 3.  The coarse levels (260 rows and fewer) then ran as a few
   // hundred waves marching 24+ rows each -- launches that are short on parallelism, not on work: levels 3 ... 8 hold 6 % of
   // the coefficients and cost 19 % of the run (timing-only DSX_SKIP_COARSE, profiles/r3_coarse_levels.txt).  4 rows per
-  // segment (2 more of halo) gives them 3-6 x the waves and a march a sixth as long: +1.5 % on the whole run.
-  static const int seg_min_rows = getenv("DSX_SEG_MIN_ROWS") ? std::max(2, atoi(getenv("DSX_SEG_MIN_ROWS"))) : 4;
+  // segment (2 more of halo) gives them 3-6 x the waves and a march a sixth as long: +0.8 % on the whole run.  Only the
+  // plain level kernels take it (coarse = true); the fused level-1 + 2 kernels keep 24 (their segments are counted in
+  // level-2 rows and carry a ring of level-1 rows: short ones come out wrong).
+  static const int seg_min_coarse = getenv("DSX_SEG_MIN_ROWS") ? std::max(2, atoi(getenv("DSX_SEG_MIN_ROWS"))) : 4;
+  const int seg_min_rows = coarse ? seg_min_coarse : 24;
   const int max_seg = std::max(1, rows / seg_min_rows);
   want = std::max(1, std::min(want, max_seg));
   if (wpb > 0 && !no_quant) {
@@ -581,7 +585,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     f.shared = ctx->stack_mode ? 1 : 0;
     f.fg_cutoff_u16 = (unsigned)std::min(65536.0, std::max(0.0, ceil((double)ctx->fg_cutoff)));
     f.nstrips = (lp.w + dsx::kMarchOut - 1) / dsx::kMarchOut;
-    march_segments(nb, f.nstrips, lp.h, &f.nseg, &f.rows_per_seg);
+    march_segments(nb, f.nstrips, lp.h, &f.nseg, &f.rows_per_seg, 0, 0, /*coarse=*/l >= 2);
     if (fuse12 && l == 0) {
       const dsx::LevelPlan& l2 = p.lv[1];
       f.aa2_off = l2.aa_off; f.da2_off = l2.da_off;
@@ -794,7 +798,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     }
     f.ablate = ctx->ablate;
     f.nstrips = (f.wout + dsx::kMarchCols - 1) / dsx::kMarchCols;
-    march_segments(nb, f.nstrips, (f.hout + 1) / 2, &f.nseg, &f.rows_per_seg);
+    march_segments(nb, f.nstrips, (f.hout + 1) / 2, &f.nseg, &f.rows_per_seg, 0, 0, /*coarse=*/l >= 2);
     const bool fused = fuse21 && last;
     if (last && split_inv) DSX_HIP(hipStreamWaitEvent(s, v.ev[3], 0));  // Delta_1, Delta_2 (helper stream)
     if (fused) {
