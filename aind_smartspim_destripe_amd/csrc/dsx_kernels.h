@@ -546,7 +546,11 @@ __device__ __forceinline__ void fwd_march_body(const Fwd1Args& a, float (*s_row)
   const FuseGeom fg = FUSE ? fuse_geom(a, strip) : FuseGeom();
   const int i2b = seg * a.rows_per_seg;
   const int i2e = FUSE ? min(a.h2, i2b + a.rows_per_seg) : 0;
-  const int i_begin = FUSE ? max(0, 2 * i2b - 4) : seg * a.rows_per_seg;
+  // The last level-2 rows of a plane mirror into level-1 rows h - 5 ... h - 1 (half-sample symmetric extension): a LAST
+  // segment of one or two level-2 rows starts above them as well, or its ring would not hold them (round 3: heights like
+  // 2390, 601 level-2 rows in 25-row segments + 1; tests::test_short_last_march_segment)
+  const int i_first = (FUSE && i2e == a.h2) ? min(2 * i2b - 4, (a.h - 6) & ~1) : 2 * i2b - 4;
+  const int i_begin = FUSE ? max(0, i_first) : seg * a.rows_per_seg;
   const int i_end = FUSE ? min(a.h, 2 * i2e) : min(a.h, i_begin + a.rows_per_seg);
   const int own_row_lo = FUSE ? 2 * i2b : i_begin;
   // steady-state level-1 rows [steady_lo, steady_hi): owned, raw rows 2i, 2i+1 inside the plane, level-2 source rows

@@ -619,6 +619,24 @@ def test_planes_wider_than_one_wave_holds(engine, shape):
             _check_plane(out[k], src[k], deltas[k], (shape, k), ref=ref, stages=stages)
 
 
+@pytest.mark.parametrize("shape", [(2390, 64), (2294, 64), (2198, 64), (626, 64), (628, 256), (578, 64)])
+def test_short_last_march_segment(engine, shape):
+    """Heights for which the LAST row segment of a march kernel is 1 ... 3 rows long (the segments are at least 24 rows,
+    the remainder is what it is): 601 / 577 / 553 level-2 rows in 25-row segments for the fused forward kernel, 313 / 314 /
+    289 coefficient rows in 26-row segments for the final kernel.  The bottom rows of such a segment mirror into rows the
+    segment above it owns; every pixel of two planes against the oracle."""
+    planes = np.stack([synth.synthetic_plane(k, *shape) for k in (0, 1)])
+    deltas = gpu_deltas(engine, planes)
+    out, cfg = filtering.destripe_planes(
+        planes, "X_0_Y_0", synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, None, synth.ZARR_PATH_HIGH_INT,
+        out_dtype=np.float32, return_config=True, max_batch=2,
+    )  # fmt: skip
+    for k in range(2):
+        which, _, _, ref, stages = oracle_plane(planes[k])
+        assert int(cfg[k]) == which
+        _check_plane(out[k], planes[k], deltas[k], (shape, k), ref=ref, stages=stages)
+
+
 def test_otsu_tie_plane(engine, capsys):
     """A plane whose level-2 class-variance curve has two maxima that agree to 1.5e-7 relative (found by
     tools/fuzz_parity.py): the reference's arg-max lands on bin 50, the engine's -- its float32 coefficients differ

@@ -33,6 +33,9 @@ def run(cases=40, seed=2026, eng=None, any_wavelet=False):
         if not any_wavelet and rng.random() < 0.03:      # rows longer than one wave holds (k_rowfilter_wide), few rows
             w = int(rng.choice([2304, 4606, 4608, 5120, 6001, 7000, 9216])) + int(rng.integers(0, 3))
             h = int(rng.integers(12, 90))
+        if not any_wavelet and rng.random() < 0.03:      # tall and narrow: many row segments, a last one of any length
+            h = int(rng.integers(2100, 4300))
+            w = (int(rng.integers(40, 76)) + 3) & ~3
         name = "db3"
         if any_wavelet:
             # (dmey is refused; rbio3.1 amplifies float32 round-off beyond 1e-4 at depth -- the reference's own float32
