@@ -410,8 +410,9 @@ void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg,
   // hundred waves marching 24+ rows each -- launches that are short on parallelism, not on work: levels 3 ... 8 hold 6 % of
   // the coefficients and cost 19 % of the run (timing-only DSX_SKIP_COARSE, profiles/r3_coarse_levels.txt).  4 rows per
   // segment (2 more of halo) gives them 3-6 x the waves and a march a sixth as long: +0.8 % on the whole run.  Only the
-  // plain level kernels take it (coarse = true); the fused level-1 + 2 kernels keep 24 (their segments are counted in
-  // level-2 rows and carry a ring of level-1 rows: short ones come out wrong).
+  // plain level kernels take it (coarse = true); the fused level-1 + 2 kernels keep 24: at the cohort sizes that matter
+  // their segment count is set by the wave target, not by this floor.  (The first attempt gave them 4 rows too and failed
+  // the GPU suite -- through last segments of one or two level-2 rows, the bug fwd_march_body's i_first now fixes.)
   static const int seg_min_coarse = getenv("DSX_SEG_MIN_ROWS") ? std::max(2, atoi(getenv("DSX_SEG_MIN_ROWS"))) : 4;
   const int seg_min_rows = coarse ? seg_min_coarse : 24;
   const int max_seg = std::max(1, rows / seg_min_rows);
