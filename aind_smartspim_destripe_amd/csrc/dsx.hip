@@ -38,8 +38,31 @@ struct ProfRec {
 
 }  // namespace
 
+// Launch-geometry switches of a context, read from the environment ONCE PER CONTEXT by dsx_init (INTEGRATION.md
+// section 6).  None of them may change a result: tools/fuzz_parity.py draws them per case (a fresh context each) and
+// tests/test_gpu_fuzz.py holds 30 such cases to the parity statement; out-of-range values are clamped here.
+struct DsxTuning {
+  int row_wpb = 0;            // DSX_ROW_WPB: waves per k_rowfilter block (0 = chosen per transform length)
+  int march_waves = 256 * 16; // DSX_MARCH_WAVES: waves a march launch aims at
+  bool no_quant = false;      // DSX_NO_QUANT: segment counts without the launch-quantisation score
+  int seg_min_rows = 4;       // DSX_SEG_MIN_ROWS: least rows per march segment of the plain level kernels
+  bool no_fuse = false;       // DSX_NO_FUSE: one forward launch per level (aa_1 materialised)
+  bool no_fuse_inv = false;   // DSX_NO_FUSE_INV: one inverse launch per level
+  bool no_pair = false;       // DSX_NO_PAIR: 8-byte pixel / result accesses in the final kernels
+  int hist_rows = 0;          // DSX_HIST_ROWS: rows per k_hist block (0 = chosen per cohort size)
+  int fwd_wpb = 8, inv_wpb = 8;  // DSX_FWD_WPB / DSX_INV_WPB: waves per block of the fused march kernels (4 or 8)
+  bool no_row_multi = false;  // DSX_NO_ROW_MULTI: one row-filter launch per coarse level
+  int row_multi_alone = 48;   // DSX_ROW_MULTI_ALONE: largest unsplit cohort that takes the merged coarse row filter
+  int helper = -1;            // DSX_HELPER: -1 = helper stream for unsplit cohorts only, 0 / 1 = never / always
+  bool no_pipeline = false;   // DSX_NO_PIPELINE: join the sub-cohort streams at every call
+#ifdef DSX_DIAG
+  int skip_hist = 0, skip_row = 0, skip_from = 1000;  // timing-only: WRONG results (DSX_SKIP_HIST / _ROW / _COARSE)
+#endif
+};
+
 struct dsx_ctx {
   int device = 0;
+  DsxTuning tune;
   hipStream_t stream_ = nullptr;  // the context ("compute") stream; entry points reach it through use_main()
   std::string err;
   bool planned = false;
@@ -167,6 +190,42 @@ struct CohortView {
 
 namespace {
 
+// the tuning of the context whose launch chain this thread is enqueueing (set by run_cohort_split / the stand-alone
+// entry points; the launch helpers below have no context argument)
+thread_local const DsxTuning* t_tune = nullptr;
+const DsxTuning& tune() {
+  static const DsxTuning defaults;
+  return t_tune ? *t_tune : defaults;
+}
+
+int env_int(const char* name, int fallback) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : fallback;
+}
+
+void read_tuning(DsxTuning& t) {
+  t.row_wpb = env_int("DSX_ROW_WPB", 0);
+  if (t.row_wpb != 0) t.row_wpb = std::max(4, std::min(t.row_wpb, (int)dsx::kRowMaxWaves));
+  t.march_waves = std::max(64, env_int("DSX_MARCH_WAVES", 256 * 16));
+  t.no_quant = env_int("DSX_NO_QUANT", 0) != 0;
+  t.seg_min_rows = std::max(2, env_int("DSX_SEG_MIN_ROWS", 4));
+  t.no_fuse = env_int("DSX_NO_FUSE", 0) != 0;
+  t.no_fuse_inv = env_int("DSX_NO_FUSE_INV", 0) != 0;
+  t.no_pair = env_int("DSX_NO_PAIR", 0) != 0;
+  t.hist_rows = std::max(0, env_int("DSX_HIST_ROWS", 0));
+  t.fwd_wpb = env_int("DSX_FWD_WPB", 8) == 4 ? 4 : 8;
+  t.inv_wpb = env_int("DSX_INV_WPB", 8) == 4 ? 4 : 8;
+  t.no_row_multi = env_int("DSX_NO_ROW_MULTI", 0) != 0;
+  t.row_multi_alone = std::max(0, env_int("DSX_ROW_MULTI_ALONE", 48));
+  t.helper = getenv("DSX_HELPER") ? (env_int("DSX_HELPER", 0) != 0 ? 1 : 0) : -1;
+  t.no_pipeline = env_int("DSX_NO_PIPELINE", 0) != 0;
+#ifdef DSX_DIAG
+  t.skip_hist = env_int("DSX_SKIP_HIST", 0);
+  t.skip_row = env_int("DSX_SKIP_ROW", 0);
+  t.skip_from = env_int("DSX_SKIP_COARSE", 1000);
+#endif
+}
+
 int fail(dsx_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
   else g_init_error = msg;  // context-free calls (dsx_io_*): dsx_last_error(NULL) reports it
@@ -257,7 +316,8 @@ hipError_t launch_rowfilter(const dsx::RowArgs& a_in, int npairs, int nb, hipStr
     if (e != hipSuccess) return e;
     attr_set[dev & 63] = true;
   }
-  static const int force_wpb = getenv("DSX_ROW_WPB") ? atoi(getenv("DSX_ROW_WPB")) : 0;
+  int force_wpb = tune().row_wpb;
+  if (force_wpb && (size_t)a_in.M * (force_wpb + 1) * sizeof(float2) > 160 * 1024) force_wpb = 0;  // would not fit the LDS
   // M >= 1024 (level 2 of the hot shapes, 77 KB per 8-wave block): 4-wave blocks of 43 KB.  Alone the kernel does not
   // care; beside the 74 KB blocks of k_rowfinal and the small coarse-level blocks three of them still find room on a CU
   // where two of the big ones do not (+0.6 % 4-stream, +1.3 % single-stream, gpurun_out/wpb_sweep.txt)
@@ -403,8 +463,8 @@ hipError_t launch_rowfilter_multi(const dsx::RowMultiArgs& a_in, const int* npai
 // halo_rows) wins (halo_rows: the rows a segment recomputes, in the units of `rows`).
 void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg, int wpb = 0, int halo_rows = 0,
                     bool coarse = false) {
-  static const int target_waves = getenv("DSX_MARCH_WAVES") ? atoi(getenv("DSX_MARCH_WAVES")) : 256 * 16;
-  static const bool no_quant = getenv("DSX_NO_QUANT") && atoi(getenv("DSX_NO_QUANT")) != 0;
+  const int target_waves = tune().march_waves;
+  const bool no_quant = tune().no_quant;
   int want = (target_waves + nb * nstrips - 1) / (nb * nstrips);
   // Rows per segment, at least: 24 until late in round 3.  The coarse levels (260 rows and fewer) then ran as a few
   // hundred waves marching 24+ rows each -- launches that are short on parallelism, not on work: levels 3 ... 8 hold 6 % of
@@ -413,7 +473,7 @@ void march_segments(int nb, int nstrips, int rows, int* nseg, int* rows_per_seg,
   // plain level kernels take it (coarse = true); the fused level-1 + 2 kernels keep 24: at the cohort sizes that matter
   // their segment count is set by the wave target, not by this floor.  (The first attempt gave them 4 rows too and failed
   // the GPU suite -- through last segments of one or two level-2 rows, the bug fwd_march_body's i_first now fixes.)
-  static const int seg_min_coarse = getenv("DSX_SEG_MIN_ROWS") ? std::max(2, atoi(getenv("DSX_SEG_MIN_ROWS"))) : 4;
+  const int seg_min_coarse = tune().seg_min_rows;
   const int seg_min_rows = coarse ? seg_min_coarse : 24;
   const int max_seg = std::max(1, rows / seg_min_rows);
   want = std::max(1, std::min(want, max_seg));
@@ -453,6 +513,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   hipStream_t s = v.stream;
   const int L = p.L;
   const int Lc = L > 0 ? L : 1;
+  t_tune = &ctx->tune;  // the launch helpers of this thread follow this context's switches
   {
     // stats: 32 B per plane; minmax: 8 Lc B per plane (parts start at even planes -> 16-byte aligned
     // except for odd Lc * po, handled by rounding the count up inside the part's own slice);
@@ -475,15 +536,15 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
 
   // ---- forward transform ------------------------------------------------------------------
   // levels 1 + 2 in one kernel when the plane allows it (aa_1 never leaves the chip)
-  static const bool no_fuse = getenv("DSX_NO_FUSE") && atoi(getenv("DSX_NO_FUSE")) != 0;
+  const bool no_fuse = ctx->tune.no_fuse;
   // any wavelet but db3: tap-count-generic level kernels, one launch per level, nothing fused
   const bool generic = ctx->wl_len > 0 && L > 0;
   const bool fuse12 = !generic && !no_fuse && L >= 2 && (p.W % 4) == 0 && (p.lv[0].ldin % 4) == 0 && p.lv[0].h >= 16 &&
                       p.lv[0].w >= 16;
-  static const bool no_fuse_inv = getenv("DSX_NO_FUSE_INV") && atoi(getenv("DSX_NO_FUSE_INV")) != 0;
+  const bool no_fuse_inv = ctx->tune.no_fuse_inv;
   const bool fuse21 = fuse12 && !no_fuse_inv;
   // uint16 planes whose rows and bases allow 16-byte pixel / result accesses by lane pairs (inv_march_body<.., PAIR>)
-  static const bool no_pair = getenv("DSX_NO_PAIR") && atoi(getenv("DSX_NO_PAIR")) != 0;
+  const bool no_pair = ctx->tune.no_pair;
   const bool pair_io = !no_pair && in_dtype == DSX_U16 && (p.W % 8) == 0 && (p.H % 2) == 0 && p.Wout == p.W &&
                        (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && ((size_t)p.H * p.W * 2) % 16 == 0;
   // level-1 row filter inside the final kernel (k_rowfinal): not for the staged debug runs, which read Delta_1 back
@@ -498,9 +559,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   // DSX_SKIP_COARSE=k: no launch for levels with index >= k (what the chain would gain if those kernels were free).
   // The results are WRONG: the switches only exist in a -DDSX_DIAG build.
 #ifdef DSX_DIAG
-  static const int skip_hist = getenv("DSX_SKIP_HIST") ? atoi(getenv("DSX_SKIP_HIST")) : 0;
-  static const int skip_row = getenv("DSX_SKIP_ROW") ? atoi(getenv("DSX_SKIP_ROW")) : 0;
-  static const int skip_from = getenv("DSX_SKIP_COARSE") ? atoi(getenv("DSX_SKIP_COARSE")) : 1000;
+  const int skip_hist = ctx->tune.skip_hist, skip_row = ctx->tune.skip_row, skip_from = ctx->tune.skip_from;
 #else
   constexpr int skip_hist = 0, skip_row = 0, skip_from = 1000;
 #endif
@@ -524,9 +583,14 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
       a.h[i] = lp.h; a.w[i] = lp.w; a.ld[i] = lp.ld;
       // rows per block: each block zeroes and folds 32 KB of counters, so big cohorts take tall blocks (128 rows: + 1-2 %
       // in the 4-stream run against 32), small ones keep enough blocks to spread over the chip (~512 per launch)
-      static const int hist_rows = getenv("DSX_HIST_ROWS") ? atoi(getenv("DSX_HIST_ROWS")) : 0;
+      const int hist_rows = ctx->tune.hist_rows;
       const int auto_rows = std::max(32, std::min(128, (int)((long long)lp.h * nb / 512)));
-      a.rows_per_block[i] = std::max(1, std::min(hist_rows > 0 ? hist_rows : auto_rows, 256));  // (16-bit per-lane counters: see k_hist)
+      // k_hist counts in 16-bit per-lane counters shared by the waves of a block: a lane sees 4 values per 16-byte load
+      // and (w >> 8) + 1 loads per row at most, and in the worst case they all fall into ONE bin (bin 0 of a plane with
+      // one outlier) -- the rows of a block are capped so that even then no counter carries into its neighbour
+      // (w = 18 432, the widest level k_rowfilter_wide admits: 227 rows)
+      const int rows_cap = std::min(256, 65535 / (4 * (lp.w >> 8) + 4));
+      a.rows_per_block[i] = std::max(1, std::min(hist_rows > 0 ? hist_rows : auto_rows, rows_cap));
       blocks += (lp.h + a.rows_per_block[i] - 1) / a.rows_per_block[i];
       a.blk_end[i] = blocks;
     }
@@ -601,7 +665,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     // 8 waves per block for the fused kernels: a block covers 8 consecutive strips of one row segment (4 KB of
     // contiguous pixels per row at 2048 columns), and at most 8 march waves sit on a CU next to the other
     // streams' row-filter blocks: +4 % in the 4-stream run (DSX_FWD_WPB / DSX_INV_WPB = 4 restores 4)
-    static const int fwd_wpb = getenv("DSX_FWD_WPB") ? atoi(getenv("DSX_FWD_WPB")) : 8;
+    const int fwd_wpb = ctx->tune.fwd_wpb;
     if (fuse12 && l == 0 && fwd_wpb == 8) {
       const dim3 g8((f.nstrips * f.nseg + 7) / 8, nb);
       if (in_dtype == DSX_U16) hipLaunchKernelGGL((dsx::k_fwd_march<0, true, 8>), g8, dim3(512), 0, s, f);
@@ -665,7 +729,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
   dsx::RowArgs row1;  // level 1, for k_rowfinal
   memset(&row1, 0, sizeof(row1));
   // coarse levels (M <= 384) that run on the part's own stream: one launch for all of them (DSX_NO_ROW_MULTI=1: one each)
-  static const bool no_multi = getenv("DSX_NO_ROW_MULTI") && atoi(getenv("DSX_NO_ROW_MULTI")) != 0;
+  const bool no_multi = ctx->tune.no_row_multi;
   dsx::RowMultiArgs multi;
   memset(&multi, 0, sizeof(multi));
   int multi_pairs[dsx::kRowMultiMax] = {};
@@ -704,7 +768,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     //  is the critical path beside the level-2 row filter on the helper stream; profiles/r3_merged_small_launches_ab.txt)
     // ... and small cohorts that run alone are launch-bound again: one plane 418 -> 358 us per call, 32 planes + 7 %,
     // 64 planes even, 128 planes - 2.7 % (profiles/r3_merged_small_launches_ab.txt); DSX_ROW_MULTI_ALONE = the limit
-    static const int multi_alone = getenv("DSX_ROW_MULTI_ALONE") ? atoi(getenv("DSX_ROW_MULTI_ALONE")) : 48;
+    const int multi_alone = ctx->tune.row_multi_alone;
     if (!no_multi && (!v.alone || nb <= multi_alone) && rs == s && a.M <= 6 * 64 && multi.nlev < dsx::kRowMultiMax) {
       multi_pairs[multi.nlev] = npairs;
       multi.lv[multi.nlev++] = a;
@@ -816,7 +880,7 @@ int run_cohort(dsx_ctx* ctx, const CohortView& v, const void* d_in, int in_dtype
     }
     dim3 grid((f.nstrips * f.nseg + 3) / 4, nb);
     LaunchScope ls(ctx, last ? KC_FINAL : KC_INV);
-    static const int inv_wpb = getenv("DSX_INV_WPB") ? atoi(getenv("DSX_INV_WPB")) : 8;
+    const int inv_wpb = ctx->tune.inv_wpb;
     if (fused && fuse_rf) {
       dsx::RowFinalArgs rf;
       rf.r = row1;
@@ -851,7 +915,7 @@ CohortView make_view(dsx_ctx* ctx, int po, hipStream_t stream, int part = 0, boo
   const int Lc = ctx->plan.L > 0 ? ctx->plan.L : 1;
   CohortView v;
   v.stream = stream;
-  static const int force_helper = getenv("DSX_HELPER") ? atoi(getenv("DSX_HELPER")) : -1;
+  const int force_helper = ctx->tune.helper;
   const bool use = force_helper >= 0 ? force_helper != 0 : helper;
   v.helper = (!use || ctx->profiling || ctx->stop_after != 0) ? nullptr : ctx->helper[part];
   v.alone = helper;
@@ -936,7 +1000,7 @@ int run_cohort_split(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void*
     if (rc != DSX_OK) return rc;
     return run_cohort(ctx, view, d_in, in_dtype, nb, d_out, out_dtype, d_cfg_used);
   }
-  static const bool no_pipe = getenv("DSX_NO_PIPELINE") && atoi(getenv("DSX_NO_PIPELINE")) != 0;
+  const bool no_pipe = ctx->tune.no_pipeline;
   auto& ls = ctx->last_split;
   const bool in_out_disjoint = (const char*)d_in + nb * in_plane <= (const char*)d_out ||
                                (const char*)d_out + nb * out_plane <= (const char*)d_in;
@@ -969,9 +1033,9 @@ int run_cohort_split(dsx_ctx* ctx, const void* d_in, int in_dtype, int nb, void*
 // by the first synchronising entry point after the kernels that found them.
 int check_sticky(dsx_ctx* ctx) {
   if (!ctx->h_sticky) return DSX_OK;
-  const unsigned f = *(volatile unsigned*)ctx->h_sticky;
+  // one atomic exchange: a kernel of another stream may be storing its 1 right now -- read-then-clear could lose it
+  const unsigned f = __atomic_exchange_n(ctx->h_sticky, 0u, __ATOMIC_ACQ_REL);
   if (f == 0u) return DSX_OK;
-  *(volatile unsigned*)ctx->h_sticky = 0u;
   return fail(ctx, DSX_EVALUE, "a plane of an earlier dsx_run_device call: autodetected range of [nan, nan] is not finite "
                                "(a float32 pixel is NaN, infinite or <= -1); that plane's result is not valid");
 }
@@ -1002,6 +1066,7 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
   if (e != hipSuccess) { g_init_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return DSX_EHIP; }
   dsx_ctx* c = new dsx_ctx();
   c->device = device;
+  read_tuning(c->tune);
 #ifdef DSX_DIAG
   if (const char* ab = getenv("DSX_ABLATE")) c->ablate = atoi(ab);
 #endif
@@ -1051,6 +1116,7 @@ int dsx_init(int device, dsx_ctx** out_ctx) {
 
 void dsx_destroy(dsx_ctx* ctx) {
   if (!ctx) return;
+  if (t_tune == &ctx->tune) t_tune = nullptr;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(use_main(ctx));
   (void)dsx_comm_destroy(ctx);
@@ -1293,6 +1359,10 @@ int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, i
     ctx->stage_out_bytes = need_out;
   }
   int32_t* d_cfg = (int32_t*)((char*)ctx->d_stage_out + out_plane * B);
+  // A value error of an EARLIER asynchronous dsx_run_device call on this context that nobody has synchronised with yet
+  // is reported now (this call synchronises) instead of being wiped by this call's own bookkeeping below.
+  DSX_HIP(hipStreamSynchronize(use_main(ctx)));
+  if (int rc = check_sticky(ctx)) return rc;
   for (int start = 0; start < n; start += B) {
     const int nb = std::min(B, n - start);
     DSX_HIP(hipMemcpyAsync(ctx->d_stage_in, (const char*)in + start * in_plane, in_plane * nb,
@@ -1313,7 +1383,9 @@ int dsx_run_host(dsx_ctx* ctx, const void* in, int in_dtype, int n, void* out, i
     if (p.L > 0) {
       std::vector<dsx::PlaneStats> hs((size_t)nb);
       DSX_HIP(hipMemcpy(hs.data(), ctx->d_stats, sizeof(dsx::PlaneStats) * nb, hipMemcpyDeviceToHost));
-      if (ctx->h_sticky) *ctx->h_sticky = 0u;  // reported right here, per plane
+      // everything before this call was synchronised and reported above: what the word holds now is this cohort's own,
+      // reported right here, per plane
+      if (ctx->h_sticky) (void)__atomic_exchange_n(ctx->h_sticky, 0u, __ATOMIC_ACQ_REL);
       for (int k = 0; k < nb && in_dtype == DSX_F32; ++k)
         if (hs[(size_t)k].flags & 1ull)
           return fail(ctx, DSX_EVALUE, "plane " + std::to_string(start + k) +
@@ -1750,7 +1822,11 @@ int dsx_png_unfilter(void* rows, int height, int stride, int bytes_per_pixel) {
 /* ---- debug hooks ---------------------------------------------------------------------------- */
 int dsx_set_stack_mode(dsx_ctx* ctx, int on) {
   if (!ctx) return DSX_EINVAL;
-  ctx->stack_mode = on != 0;
+  const bool want = on != 0;
+  // the mode is baked into captured launch chains (Fwd1Args / HistArgs / OtsuArgs::shared) and is not part of the
+  // graph cache's key: a graph captured under the other mode must not be replayed
+  if (want != ctx->stack_mode) drop_graphs(ctx);
+  ctx->stack_mode = want;
   return DSX_OK;
 }
 int dsx_set_stop_after(dsx_ctx* ctx, int stage) {

@@ -268,10 +268,13 @@ inline std::string build_plan(int H, int W, const HostCfg cfg[2], Plan& p, int f
       }
     }
     // measurement hook (tools/plan_direct_vs_embedded.sh): DSX_PLAN_DIRECT_LEVEL=<l> forces the direct
-    // length-n transform at level index l whatever the cost model says
+    // length-n transform at level index l whatever the cost model says -- another transform, other roundings: only in
+    // a -DDSX_DIAG build (tools/build_variant.sh), the product has no such switch
+#ifdef DSX_DIAG
     if (const char* fd = getenv("DSX_PLAN_DIRECT_LEVEL")) {
       if (atoi(fd) == l && n <= kMaxFftLen) { best_m = n; best_k = 0; }
     }
+#endif
     if (best_k > 0) {
       for (int c = 0; c < 2; ++c) {
         h1[c] = idft_even(ep[c]);

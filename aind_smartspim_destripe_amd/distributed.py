@@ -13,8 +13,11 @@ Two transports:
   ``include/dsx.h``, ``librccl.so`` dlopen'ed by the engine; no torch).  The 128-byte unique id goes
   from rank 0 to the other ranks through :class:`FileRendezvous` (one node) or any channel the
   caller has; ``torchrun`` is only the launcher that sets ``RANK`` / ``LOCAL_RANK`` / ``WORLD_SIZE``.
-* a ``torch.distributed`` process group passed in by the caller (``broadcast_array`` & co.): ``gloo``
-  for the CPU tests of the sharding logic, ``nccl`` (== RCCL) if a host program already has one.
+* the same protocol on the HOST (``transport == "host"``): when the communicator cannot be built on some rank, every
+  rank agrees (over the rendezvous) to reduce / broadcast through the rendezvous directory instead.
+
+No torch anywhere in the product: the ``torch.distributed`` (gloo) helpers the CPU tests of the sharding logic use
+live in ``tests/dist_helpers.py``.
 """
 
 import hashlib
@@ -57,8 +60,9 @@ class FileRendezvous:
         self.dir = directory
         self.prefix = ""
         os.makedirs(self.dir, mode=0o700, exist_ok=True)
-        st = os.stat(self.dir)
-        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        # lstat, not stat: a symlink planted under the predictable name must not pass for the directory it points at
+        st = os.lstat(self.dir)
+        if stat.S_ISLNK(st.st_mode) or not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
             raise RuntimeError(
                 "rendezvous directory {} is not a private directory of this user (owner uid {}, mode {:o}); "
                 "set DSX_RDZV_DIR to a directory of your own".format(self.dir, st.st_uid, st.st_mode & 0o777))
@@ -95,7 +99,8 @@ class FileRendezvous:
         if self.rank != 0:
             return
         for f in os.listdir(self.dir):
-            if self.prefix and not f.startswith(self.prefix):
+            # this group's keys, and temporary files a put() that died left behind (nobody renames them any more)
+            if self.prefix and not (f.startswith(self.prefix) or f.startswith(".tmp_")):
                 continue
             try:
                 os.remove(os.path.join(self.dir, f))
@@ -239,6 +244,48 @@ class RankGroup:
                     self.rank, "" if not mine_ok else " on another rank"))
         return nbytes
 
+    def broadcast_json(self, obj, root=0):
+        """Small host-side metadata (shapes, a status, a tile config) from ``root`` to every rank, as JSON through the
+        rendezvous directory -- whatever the transport: it is a few hundred bytes and never on the data path."""
+        if not self.active:
+            return obj
+        import json
+
+        self._seq += 1
+        key = "bj.{}".format(self._seq)
+        if self.rank == root:
+            self.rdzv.put(key, json.dumps(obj).encode())
+            return obj
+        return json.loads(self.rdzv.get(key).decode())
+
+    def broadcast_array(self, array, dtype, shape, root=0):
+        """A NumPy array held by ``root`` (``array`` is ignored elsewhere) -> a host copy on every rank.
+
+        Transport "rccl": the bytes cross the node as ONE RCCL broadcast between device buffers (xGMI); transport
+        "host": through one file of the rendezvous directory.  ``dtype`` / ``shape`` must agree on all ranks
+        (:meth:`broadcast_json` carries them)."""
+        dtype, shape = np.dtype(dtype), tuple(int(n) for n in shape)
+        if not self.active:
+            return np.ascontiguousarray(array, dtype=dtype).reshape(shape)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        if self.transport == "host":
+            self._seq += 1
+            key = "ba.{}".format(self._seq)
+            if self.rank == root:
+                a = np.ascontiguousarray(array, dtype=dtype).reshape(shape)
+                self.rdzv.put(key, a.tobytes())
+                return a
+            return np.frombuffer(self.rdzv.get(key), dtype=dtype).reshape(shape).copy()
+        d = self.engine.alloc(max(nbytes, 16))
+        try:
+            if self.rank == root:
+                a = np.ascontiguousarray(array, dtype=dtype).reshape(shape)
+                d.upload(a)
+            self.broadcast_device(d, nbytes, root)
+            return a if self.rank == root else d.download(shape, dtype)
+        finally:
+            d.free()
+
     def broadcast_shading(self, flatfield, darkfield, shape_flat, shape_dark, root=0):
         """Rank ``root`` holds the flat / dark planes of a tile; every rank gets device copies
         (``dsx_set_shading_device``).  Returns the two DeviceBuffers (caller frees them)."""
@@ -314,39 +361,3 @@ def z_shard(n_slices, world_size, rank, z_chunk=64):
     start = min(first * z_chunk, n_slices)
     stop = min((first + count) * z_chunk, n_slices)
     return start, stop
-
-
-def broadcast_array(dist, array, src=0, device=None):
-    """Broadcast a NumPy array from ``src`` (shape and dtype must already agree on all ranks).
-
-    ``device=None`` uses a host tensor (gloo); ``device='cuda'`` stages through a device tensor so
-    that the transfer is an RCCL broadcast over xGMI.
-    """
-    import torch
-
-    a = np.ascontiguousarray(array)
-    t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy())
-    if device is not None:
-        t = t.to(device)
-    dist.broadcast(t, src=src)
-    out = t.cpu().numpy().view(a.dtype).reshape(a.shape)
-    return out
-
-
-def broadcast_shading(dist, flatfield, darkfield, shape_flat, shape_dark, src=0, device=None):
-    """Rank ``src`` holds the retrospective flat / dark planes of a tile; every rank gets a copy."""
-    rank = dist.get_rank()
-    flat = np.asarray(flatfield, dtype=np.float32) if rank == src else np.empty(shape_flat, np.float32)
-    dark = np.asarray(darkfield, dtype=np.float32) if rank == src else np.empty(shape_dark, np.float32)
-    return broadcast_array(dist, flat, src, device), broadcast_array(dist, dark, src, device)
-
-
-def reduce_counters(dist, slices_done, seconds):
-    """Sum of slices and max of elapsed time over ranks -> whole-job slices/s."""
-    import torch
-
-    t = torch.tensor([float(slices_done)], dtype=torch.float64)
-    m = torch.tensor([float(seconds)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    dist.all_reduce(m, op=dist.ReduceOp.MAX)
-    return float(t[0]), float(m[0])

@@ -239,6 +239,14 @@ def get_engine(shape, cells_config, no_cells_config, microscope_high_int=2700, f
     return e
 
 
+def release_engines():
+    """Close every cached engine of this process (their workspaces go back to the device; a later call plans anew and
+    its context reads the ``DSX_*`` switches of the environment again)."""
+    while _ENGINES:
+        _, old = _ENGINES.popitem(last=False)
+        old[0].close()
+
+
 def _array_key(a):
     a = np.asarray(a)
     return (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str)

@@ -58,9 +58,10 @@ def compute_pyramid(data, n_lvls, scale_axis, chunks="auto", device=0, engine=No
     return levels
 
 
-def compute_multiscale(level0_path, group_path, scale_factor=(2, 2, 2), n_levels=3, chunks=(1, 1, 64, 128, 128),
+def write_pyramid_levels(level0_path, group_path, scale_factor=(2, 2, 2), n_levels=3, chunks=(1, 1, 64, 128, 128),
                        compressor="blosc", device=0, slab_planes=None):  # fmt: skip
-    """Level loop of ``compute_multiscale`` (``zarr_destriper.py:746-782``) over Zarr-v2 directory stores:
+    """Level loop of ``compute_multiscale`` (``zarr_destriper.py:746-782``) over Zarr-v2 directory stores
+    (``zarr_destriper.compute_multiscale`` is the entry point with the reference's signature and calls this):
     writes ``<group_path>/<i>`` for ``i = 1 .. n_levels - 1`` (uint16, ``"/"`` separator), every level from the
     previous one.  OME-NGFF metadata (``:728-742``) is out of scope.  Returns the written arrays' shapes.
 

@@ -4,15 +4,21 @@ Mirrors the boundary of ``/root/reference/code/aind_smartspim_destripe/zarr_dest
 hot path sees: :func:`execute_worker` (reference ``:253-336``) has the reference's signature and
 writes the filtered block into the output array exactly where the reference does.  The producer /
 consumer process pool (``:797-906``) becomes a plain loop over z-blocks per rank
-(:func:`destripe_zarr`): one process per GPU owns a contiguous, chunk-aligned z-range
+(:func:`destripe_zarr_store`): one process per GPU owns a contiguous, chunk-aligned z-range
 (``distributed.z_shard``), so no queue and no pickled 819 MB blocks are needed.
+
+The two public entry points above it keep the reference's parameter lists -- :func:`destripe_channel`
+(``:1214-1223``, called by keyword from ``run_capsule.py:394-403``) and :func:`destripe_zarr` (``:909-924``) -- with
+the engine's extras keyword-only behind them, and ``compute_pyramid`` / ``compute_multiscale`` are reachable under
+the reference's module name (``tests/test_reference_signatures.py`` holds every same-named function to the
+reference's signature).
 
 ``recover_global_position`` / ``unpad_global_coords`` belong to the third-party package
 ``aind_large_scale_prediction==1.0.0`` (``zarr_destriper.py:22-24``), which is not vendored in the
 reference and not installed here; their behaviour is restated from the call site (``:268-312``) and is
 exact for the production setting ``overlap_prediction_chunksize=(0, 0, 0)`` (``:1018-1022``).
 
-Row f1 of SURVEY section 8: when the store holds uint16 bricks, :func:`destripe_zarr` uploads the
+Row f1 of SURVEY section 8: when the store holds uint16 bricks, :func:`destripe_zarr_store` uploads the
 decompressed chunks as they lie in the store and re-tiles them into planes (and the filtered planes back
 into bricks) on the device (``dsx_bricks_to_planes_u16`` / ``dsx_planes_to_bricks_u16``), so the host only
 (de)compresses -- no NumPy gather / scatter of 128 x 128 tiles.  The multiscale pyramid is in ``pyramid.py``.
@@ -370,6 +376,7 @@ class _DeviceBlocks:
         return sum(z1 - z0 for z0, z1 in blocks)
 
 
+LAST_RUN = {}  # what the last destripe_zarr_store call of this process resolved to (rank, z-range, codec threads): diagnostics
 _BLOCKS = {}  # one set of staging buffers per process: page-locking 2 GB of host memory costs ~0.4 s per call
 
 
@@ -414,7 +421,7 @@ def _device_retile_ok(src, dst, zyx, block_z, z0, z1):
     )
 
 
-def destripe_zarr(
+def destripe_zarr_store(
     dataset_path,
     output_path,
     cells_config,
@@ -432,7 +439,9 @@ def destripe_zarr(
     tile_name=None,
     group=None,
 ):
-    """Chunk map of ``destripe_zarr`` (``zarr_destriper.py:909-1211``) over a Zarr-v2 directory store.
+    """Chunk map of ``destripe_zarr`` (``zarr_destriper.py:909-1211``) over a Zarr-v2 directory store -- the engine-level
+    form (explicit configs and ``shadow_correction``); :func:`destripe_zarr` is the entry point with the reference's
+    signature and calls this.
 
     ``compressor``: codec of the output array; the default is the reference's,
     ``Blosc(cname="zstd", clevel=3, shuffle=SHUFFLE)`` (``:1066-1074``); ``None`` (raw chunks), ``"zlib"`` or a
@@ -452,8 +461,8 @@ def destripe_zarr(
     left-over with the same geometry and codec is indistinguishable and harmless: rank 0 rewrites the same
     metadata, every rank rewrites its own chunks).  ``device=None`` takes the local rank (``LOCAL_RANK``), not the global one.
 
-    ``io_threads``: native threads that read / decompress and compress / write chunks (default: the cores this
-    process may run on).
+    ``io_threads``: native threads that read / decompress and compress / write chunks (default:
+    :func:`default_io_threads` -- the cores this process may run on divided among the ranks of the node).
 
     ``device_retile``: ``True`` = chunks are re-tiled into planes and back on the GPU (row f1; needs a
     uint16 store and chunk-aligned z blocks), ``False`` = host gather / scatter through
@@ -461,13 +470,7 @@ def destripe_zarr(
     """
     logger = logger or logging.getLogger("dsx.zarr")
     if io_threads is None:
-        # the chunk codecs are the bottleneck of this path (zstd level 5 runs at ~0.7 GB/s per core, the filter at
-        # > 500 GB/s): every core this process may use, as the reference's CO_CPUS consumers (zarr_destriper.py:1138)
-        try:
-            io_threads = len(os.sched_getaffinity(0))
-        except (AttributeError, OSError):
-            io_threads = os.cpu_count() or 8
-        io_threads = max(1, min(int(io_threads), 64))
+        io_threads = default_io_threads(world_size)
     src = MiniZarrArray.open(dataset_path)
     zyx = src.shape[-3:]
     if prediction_chunksize[1] < zyx[1] or prediction_chunksize[2] < zyx[2]:
@@ -493,6 +496,7 @@ def destripe_zarr(
         raise TimeoutError("rank {}: the output array {} was not created with shape {}".format(rank, output_path, out_shape))
     z0, z1 = z_shard(zyx[0], world_size, rank, z_chunk=output_chunks[-3])
     dev = int(os.environ.get("LOCAL_RANK", rank)) if device is None else device
+    LAST_RUN.update(rank=rank, world_size=world_size, z_range=(z0, z1), io_threads=int(io_threads), device=dev)
     # dataset_name of the reference = the tile folder (X_..._Y_....zarr), also when level "0" is opened
     name = tile_name or os.path.basename(str(dataset_path).rstrip("/"))
     n_planes, t0 = 0, time.perf_counter()
@@ -523,14 +527,262 @@ def destripe_zarr(
     return n_planes, dt
 
 
+def default_io_threads(world_size=1):
+    """Codec threads of ONE rank: the cores this process may run on, shared among the ranks of the node.
+
+    The chunk codecs are the bottleneck of this path (zstd level 5 runs at ~0.7 GB/s per core, the filter at
+    > 500 GB/s), so a rank takes every core it can -- as the reference's ``CO_CPUS`` consumers do
+    (``zarr_destriper.py:1091, 1138``) -- but eight ranks on one node must not take every core eight times:
+    the budget is ``cores // LOCAL_WORLD_SIZE`` (``LOCAL_WORLD_SIZE`` as set by ``torchrun``, else ``world_size``:
+    one node), at least 2, at most 64.
+    """
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 8
+    local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world_size) or 1))
+    return max(2, min(cores // local, 64))
+
+
+def _cpu_limit():
+    """``utils.get_code_ocean_cpu_limit`` (``utils/utils.py:197-226``): ``CO_CPUS``, else the cores of this process."""
+    co_cpus = os.environ.get("CO_CPUS")
+    if co_cpus:
+        return int(co_cpus)
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def _broadcast_planes(group, rank, world_size, read):
+    """``read()`` (a dict of arrays / ``None``) runs on rank 0 only; every rank gets the arrays.
+
+    ``group`` with ``broadcast_array`` / ``broadcast_json`` (``distributed.RankGroup``): the planes travel as ONE
+    collective per array -- RCCL over xGMI, or the rendezvous directory on the host transport -- instead of every rank
+    reading the same TIFF files (the reference reads them once per tile, ``zarr_destriper.py:1099-1130, 1249``).  An
+    exception of rank 0's ``read`` is re-raised on EVERY rank (nobody is left waiting in a collective).  Any other
+    group (or a single rank): every rank reads for itself.
+    """
+    if world_size <= 1 or not (hasattr(group, "broadcast_array") and hasattr(group, "broadcast_json")):
+        return read()
+    status, planes = {"ok": True}, {}
+    if rank == 0:
+        try:
+            planes = read()
+            status["keys"] = {k: (None if v is None else [np.asarray(v).dtype.str, list(np.asarray(v).shape)])
+                              for k, v in planes.items()}  # fmt: skip
+        except Exception as e:  # noqa: BLE001 - handed to every rank below
+            status = {"ok": False, "type": type(e).__name__, "error": str(e)}
+    status = group.broadcast_json(status, root=0)
+    if not status["ok"]:
+        exc = {"FileNotFoundError": FileNotFoundError, "ValueError": ValueError, "KeyError": KeyError}.get(
+            status["type"], RuntimeError)
+        raise exc(status["error"])
+    out = {}
+    for k in sorted(status["keys"]):
+        meta = status["keys"][k]
+        if meta is None:
+            out[k] = None
+            continue
+        src = np.ascontiguousarray(planes[k]) if rank == 0 else None
+        out[k] = group.broadcast_array(src, np.dtype(meta[0]), tuple(meta[1]), root=0)
+    return out
+
+
+def compute_pyramid(data, n_lvls, scale_axis, chunks="auto", device=0, engine=None):
+    """``zarr_destriper.py:365-407`` (re-exported under the reference's module name; the kernel side is ``pyramid.py``)."""
+    from . import pyramid
+
+    return pyramid.compute_pyramid(data, n_lvls, scale_axis, chunks=chunks, device=device, engine=engine)
+
+
+def compute_multiscale(
+    output_zarr,
+    zarr_group,
+    scale_factor,
+    n_workers,
+    voxel_size,
+    image_name,
+    n_levels=3,
+    threads_per_worker=1,
+    *,
+    chunks=(1, 1, 64, 128, 128),
+    compressor="blosc",
+    device=0,
+    slab_planes=None,
+):
+    """``compute_multiscale`` of the reference (``zarr_destriper.py:677-794``) with its signature.
+
+    ``output_zarr``: level 0 (a :class:`MiniZarrArray` or its path); ``zarr_group``: the group folder the levels
+    ``1 .. n_levels - 1`` are written into (a path, or anything with ``.path``).  ``n_workers`` /
+    ``threads_per_worker`` sized the reference's dask ``LocalCluster`` (``:689-697``) and ``voxel_size`` /
+    ``image_name`` feed its OME-NGFF metadata (``:728-742``): accepted, not used -- one HIP kernel per level replaces the
+    cluster, the metadata is out of scope.  Returns the shapes of the written levels.
+    """
+    from . import pyramid
+
+    del n_workers, voxel_size, image_name, threads_per_worker
+    level0 = getattr(output_zarr, "path", output_zarr)
+    group_path = getattr(zarr_group, "path", zarr_group)
+    return pyramid.write_pyramid_levels(str(level0), str(group_path), scale_factor=tuple(scale_factor), n_levels=n_levels,
+                                        chunks=chunks, compressor=compressor, device=device, slab_planes=slab_planes)  # fmt: skip
+
+
+def destripe_zarr(
+    dataset_path,
+    multiscale,
+    output_destriped_zarr,
+    prediction_chunksize,
+    target_size_mb,
+    n_workers,
+    batch_size,
+    super_chunksize,
+    results_folder,
+    derivatives_path,
+    xyz_resolution,
+    parameters,
+    flatfield=None,
+    lazy_callback_fn=None,
+    *,
+    rank=0,
+    world_size=1,
+    device=None,
+    compressor="blosc",
+    output_chunks=(1, 1, 64, 128, 128),
+    n_levels=3,
+    logger=None,
+    device_retile=None,
+    io_threads=None,
+    group=None,
+):
+    """``destripe_zarr`` of the reference (``zarr_destriper.py:909-1211``) with its 14 parameters, on the GPU chunk map.
+
+    What the reference does with them, and what happens here:
+
+    * ``dataset_path`` / ``multiscale``: the tile ``.zarr`` and the level to process (``:1027-1035``) -- level
+      ``<dataset_path>/<multiscale>`` is opened (or ``dataset_path`` itself when it already is an array).
+    * ``output_destriped_zarr``: a group of that name is created with array ``0`` in it (``:1060-1075``: uint16, chunks
+      ``(1, 1, 64, 128, 128)``, Blosc-zstd level 3 with byte shuffle, ``"/"`` separator, always anew) and levels
+      ``1 .. 2`` of the pyramid next to it (``:1176-1192``, ``n_levels=3``).
+    * ``prediction_chunksize``: z-block of the chunk map; blocks must cover whole planes (the filter is per plane).
+    * ``parameters``: ``cells_config`` / ``no_cells_config`` (``:972-973``, ``KeyError`` without them).
+    * ``derivatives_path`` / ``flatfield``: the ``shadow_correction`` dict is built as ``:1095-1130`` does
+      (:func:`load_shadow_correction`: ``DarkMaster_cropped.tif``, retrospective flat if given, else the
+      normalised microscope flats + tile config); no derivatives folder and no flat = no shading correction.
+    * ``n_workers``: ``ValueError`` when above the CPU limit, like ``:977-978``; otherwise unused -- so are
+      ``target_size_mb``, ``batch_size``, ``super_chunksize`` (sizing of the reference's data loader, ``:1041-1057``),
+      ``results_folder`` (log file and resource plots, ``:980, 1202-1211``) and ``xyz_resolution`` (OME-NGFF voxel size,
+      ``:1181-1185``): loader, logging and metadata are out of scope.
+    * ``lazy_callback_fn``: applied by the reference's loader to the lazy array (``:1052``); ``None`` in production
+      (``:1266``).  Anything else raises ``NotImplementedError`` -- silently skipping a transform would change the data.
+
+    Keyword-only extras (the engine's): ``rank`` / ``world_size`` / ``group`` (one process per GPU, chunk-aligned
+    z-ranges; with a ``distributed.RankGroup`` rank 0 alone reads the dark plane and broadcasts it), ``device``,
+    ``compressor`` / ``output_chunks`` of the output, ``n_levels``, ``device_retile``, ``io_threads``.
+    Returns ``(planes processed by this rank, seconds)``.
+    """
+    no_cells_config = parameters["no_cells_config"]
+    cells_config = parameters["cells_config"]
+    co_cpus = _cpu_limit()
+    if n_workers > co_cpus:
+        raise ValueError(f"Provided workers {n_workers} > current workers {co_cpus}")
+    if lazy_callback_fn is not None:
+        raise NotImplementedError("lazy_callback_fn: the GPU chunk map reads the store as it is (production passes None)")
+    del target_size_mb, batch_size, super_chunksize, results_folder
+    logger = logger or logging.getLogger("dsx.zarr")
+    logger.info(f"Processing dataset {dataset_path}")
+    dataset_path = Path(dataset_path)
+    output_destriped_zarr = Path(output_destriped_zarr)
+    level = dataset_path.joinpath(str(multiscale))
+    src = level if level.joinpath(".zarray").exists() else dataset_path
+    dataset_name = output_destriped_zarr.name
+    derivatives_path = Path(derivatives_path)
+
+    def read_shading():
+        sc = load_shadow_correction(derivatives_path, output_destriped_zarr, flatfield, logger)
+        return {"darkfield": sc["darkfield"], "microscope_flats": None if sc["retrospective"] else sc["flatfield"],
+                "tile_config": sc["tile_config"]}  # fmt: skip
+
+    if world_size > 1 and hasattr(group, "broadcast_array"):
+        tile_config = {}
+
+        def read_planes():
+            got = read_shading()
+            tile_config["v"] = got.pop("tile_config")
+            return got
+
+        planes = _broadcast_planes(group, rank, world_size, read_planes)
+        tc = group.broadcast_json(tile_config.get("v"), root=0)
+        shadow_correction = {
+            "retrospective": flatfield is not None,
+            "flatfield": flatfield if flatfield is not None else planes["microscope_flats"],
+            "darkfield": planes["darkfield"],
+            "tile_config": tc,
+        }
+    else:
+        shadow_correction = load_shadow_correction(derivatives_path, output_destriped_zarr, flatfield, logger)
+    if shadow_correction["flatfield"] is None:
+        if shadow_correction["darkfield"] is not None:
+            # the reference would hand flatfield=None to flatfield_correction and fail inside NumPy (filtering.py:371-391)
+            raise ValueError("a darkfield without a flatfield: give `flatfield` or put FlatReal*.tif + metadata.json into "
+                             f"{derivatives_path}")  # fmt: skip
+        shadow_correction = None
+    elif shadow_correction["darkfield"] is None:
+        # flatfield_correction dereferences the dark plane (filtering.py:371-377): nothing to correct with
+        raise ValueError(f"No darkfield for the shading correction: {derivatives_path} does not exist")
+    level0 = output_destriped_zarr.joinpath("0")
+    n_planes, seconds = destripe_zarr_store(
+        str(src),
+        str(level0),
+        cells_config,
+        no_cells_config,
+        shadow_correction=shadow_correction,
+        prediction_chunksize=tuple(prediction_chunksize),
+        output_chunks=output_chunks,
+        rank=rank,
+        world_size=world_size,
+        device=device,
+        compressor=compressor,
+        logger=logger,
+        device_retile=device_retile,
+        io_threads=io_threads,
+        tile_name=dataset_name,
+        group=group,
+    )
+    if group is not None and world_size > 1:
+        group.barrier()  # level 0 of this tile is complete on every rank: the pyramid may read it
+    if rank == 0 and n_levels > 1:
+        dev = int(os.environ.get("LOCAL_RANK", rank)) if device is None else device
+        t0 = time.perf_counter()
+        compute_multiscale(
+            output_zarr=str(level0),
+            zarr_group=str(output_destriped_zarr),
+            scale_factor=[2, 2, 2],
+            n_workers=co_cpus,
+            voxel_size=[xyz_resolution[-1], xyz_resolution[-2], xyz_resolution[-3]] if xyz_resolution is not None else None,
+            image_name=dataset_name,
+            n_levels=n_levels,
+            threads_per_worker=1,
+            chunks=output_chunks,
+            compressor=compressor,
+            device=dev,
+        )
+        logger.info(f"Processing multiscale time: {time.perf_counter() - t0} seconds")
+    logger.info(f"Processing destripe flatfield time: {seconds} seconds")
+    return n_planes, seconds
+
+
 def destripe_channel(
     zarr_dataset_path,
     derivatives_path,
     channel_name,
     results_folder,
+    xyz_resolution,
     estimated_channel_flats,
     laser_tiles,
     parameters,
+    *,
     multiscale="0",
     prediction_chunksize=(64, 1600, 2000),
     output_chunks=(1, 1, 64, 128, 128),
@@ -541,67 +793,70 @@ def destripe_channel(
     n_levels=3,
     logger=None,
     group=None,
+    io_threads=None,
+    device_retile=None,
 ):
-    """Tile loop of ``destripe_channel`` (``zarr_destriper.py:1214-1267``) wired to the GPU chunk map.
+    """``destripe_channel`` of the reference (``zarr_destriper.py:1214-1267``), same eight parameters (the reference's
+    caller passes them by keyword, ``run_capsule.py:394-403``), wired to the GPU chunk map.
 
     For every ``<channel>/<tile>.zarr``: pick the retrospective flat of the laser side the tile belongs to
-    (``laser_tiles`` = ``{side: [tile stems]}``, ``ValueError`` for a tile in neither, ``:1239-1247``), build the
-    ``shadow_correction`` dict (:func:`load_shadow_correction`), destripe level ``multiscale`` into
-    ``<results>/destriped_data/<channel>/<tile>.zarr/0`` and, on rank 0, write pyramid levels ``1 .. n_levels - 1``
-    (``compute_multiscale``, ``:1176-1192``).  ``parameters`` holds ``cells_config`` / ``no_cells_config``
-    (``:972-973``).  Returns ``{tile name: planes processed by this rank}``.
+    (``laser_tiles`` = ``{side: [tile stems]}``, ``ValueError`` for a tile in neither, ``:1239-1247``), read it
+    (``:1249``) and call :func:`destripe_zarr` with the reference's arguments (``:1252-1267``):
+    ``<results>/destriped_data/<channel>/<tile>.zarr/0`` plus pyramid levels ``1 .. n_levels - 1``.
+    ``xyz_resolution`` only feeds OME-NGFF metadata in the reference (out of scope): accepted, handed on.
+    Returns ``{tile name: planes processed by this rank}``.
 
-    ``world_size > 1`` needs ``group`` (anything with ``barrier()``): the pyramid of a tile may only be
-    computed once EVERY rank has written its z-range, so rank 0 waits on the group before it starts it.
-    A derivatives folder without ``DarkMaster_cropped.tif`` raises (``load_shadow_correction``); no
-    derivatives folder at all leaves ``darkfield=None``, which the reference cannot correct with either
-    (``flatfield_correction`` dereferences it, ``filtering.py:371-377``) -- ``ValueError`` here.
+    Keyword-only extras: ``rank`` / ``world_size`` / ``group`` / ``device`` (one process per GPU), output codec and
+    chunks, ``multiscale`` (the reference hard-codes ``"0"``), ``prediction_chunksize`` (the reference hard-codes the
+    production tile, ``(64, 1600, 2000)``), ``io_threads``, ``device_retile``.  ``world_size > 1`` needs ``group`` (anything with
+    ``barrier()``): the pyramid of a tile may only be computed once EVERY rank has written its z-range.  With a
+    ``distributed.RankGroup`` rank 0 alone reads the flat and dark planes of a tile and broadcasts them (RCCL).
     """
     if world_size > 1 and group is None:
         raise ValueError("destripe_channel with world_size > 1 needs a group to order the pyramid after all ranks")
-    from . import pyramid
-
     logger = logger or logging.getLogger("dsx.zarr")
-    channel_dataset = Path(zarr_dataset_path).joinpath(channel_name)
-    destriped_data_folder = Path(results_folder).joinpath("destriped_data")
+    zarr_dataset_path, results_folder = Path(zarr_dataset_path), Path(results_folder)
+    channel_dataset = zarr_dataset_path.joinpath(channel_name)
+    destriped_data_folder = results_folder.joinpath("destriped_data")
     os.makedirs(destriped_data_folder, exist_ok=True)
     done = {}
     for tile_path in sorted(channel_dataset.glob("*.zarr")):
         output_folder = destriped_data_folder.joinpath(f"{channel_name}/{tile_path.name}")
+        logger.info(f"Processing {tile_path} - writing to: {output_folder} - derivatives: {derivatives_path}")
         flatfield_path = None
+        tile_stem = tile_path.stem.rsplit(".", 1)[0]
         for side, tiles in laser_tiles.items():
-            tile_path_stem = tile_path.stem.rsplit(".", 1)[0]
-            if tile_path_stem in tiles:
+            if tile_stem in tiles:
                 flatfield_path = estimated_channel_flats[int(side)]
                 break
         if flatfield_path is None:
             raise ValueError(f"Tile {tile_path} not found in {laser_tiles}")
-        flatfield = tif.imread(str(flatfield_path))
-        shadow_correction = load_shadow_correction(derivatives_path, output_folder, flatfield, logger)
-        if shadow_correction["darkfield"] is None:
-            raise ValueError(f"No darkfield for the shading correction: {derivatives_path} does not exist")
-        src = tile_path.joinpath(multiscale) if tile_path.joinpath(multiscale, ".zarray").exists() else tile_path
+        flatfield = _broadcast_planes(group, rank, world_size, lambda: {"flat": tif.imread(str(flatfield_path))})["flat"]
         n, _ = destripe_zarr(
-            str(src),
-            str(output_folder.joinpath("0")),
-            parameters["cells_config"],
-            parameters["no_cells_config"],
-            shadow_correction=shadow_correction,
+            dataset_path=tile_path,
+            multiscale=multiscale,
+            output_destriped_zarr=output_folder,
             prediction_chunksize=prediction_chunksize,
-            output_chunks=output_chunks,
+            target_size_mb=3072,
+            n_workers=0,
+            batch_size=1,
+            super_chunksize=(384, 1600, 2000),
+            results_folder=results_folder,
+            derivatives_path=derivatives_path,
+            xyz_resolution=xyz_resolution,
+            parameters=parameters,
+            flatfield=flatfield,
+            lazy_callback_fn=None,
             rank=rank,
             world_size=world_size,
             device=device,
             compressor=compressor,
+            output_chunks=output_chunks,
+            n_levels=n_levels,
             logger=logger,
-            tile_name=tile_path.name,
+            io_threads=io_threads,
+            device_retile=device_retile,
             group=group,
         )
         done[tile_path.name] = n
-        if group is not None and world_size > 1:
-            group.barrier()  # level 0 of this tile is complete on every rank
-        if rank == 0 and n_levels > 1:
-            dev = int(os.environ.get("LOCAL_RANK", rank)) if device is None else device
-            pyramid.compute_multiscale(str(output_folder.joinpath("0")), str(output_folder), n_levels=n_levels,
-                                       chunks=output_chunks, compressor=compressor, device=dev)  # fmt: skip
     return done

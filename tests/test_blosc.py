@@ -355,7 +355,7 @@ def test_gpu_chunk_map_on_a_production_style_blosc_store(tmp_path):
         src[0, 0] = stack
         for mode in (False, True):
             path = str(tmp_path / "out_{}_{}.zarr".format(comp, int(mode)))
-            n, _ = zd.destripe_zarr(str(tmp_path / "in_{}.zarr".format(comp)), path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG,
+            n, _ = zd.destripe_zarr_store(str(tmp_path / "in_{}.zarr".format(comp)), path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG,
                                     prediction_chunksize=(8, 96, 128), output_chunks=(1, 1, 8, 32, 32), device=0,
                                     device_retile=mode, compressor=comp)  # fmt: skip
             assert n == 20

@@ -37,8 +37,10 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
     import torch.distributed as dist
 
+    import dist_helpers as dh
     from aind_smartspim_destripe_amd import distributed as dd
     from aind_smartspim_destripe_amd import synth
 
@@ -50,7 +52,7 @@ def _worker(rank, world, port, q):
         rs = np.random.RandomState(3)
         flat0 = (0.5 + rs.rand(32, 48)).astype(np.float32)
         dark0 = (100 * rs.rand(40, 50)).astype(np.float32)
-        flat, dark = dd.broadcast_shading(dist, flat0 if rank == 0 else None, dark0 if rank == 0 else None,
+        flat, dark = dh.broadcast_shading(dist, flat0 if rank == 0 else None, dark0 if rank == 0 else None,
                                           (32, 48), (40, 50))  # fmt: skip
         ok_bcast = bool(np.array_equal(flat, flat0) and np.array_equal(dark, dark0))
         # z-sharding of a 200-slice stack with 64-slice chunks; each rank "processes" its own planes
@@ -59,7 +61,7 @@ def _worker(rank, world, port, q):
         checksum = 0
         for z in range(s, e):
             checksum += int(synth.synthetic_plane(z % 4, 16, 16).astype(np.uint64).sum()) * (z + 1)
-        total, tmax = dd.reduce_counters(dist, e - s, 1.0 + rank)
+        total, tmax = dh.reduce_counters(dist, e - s, 1.0 + rank)
         q.put((rank, s, e, checksum, ok_bcast, total, tmax))
     finally:
         dist.destroy_process_group()
@@ -194,6 +196,13 @@ def _rankgroup_worker(rank, world, xdir, corrupt, q):
         try:
             n = grp.broadcast_constants(root=0)
             tot = grp.allreduce([float(rank + 1)], "sum")[0]
+            # metadata over the rendezvous, a plane over the (fake) device broadcast: only rank 0 holds them
+            meta = grp.broadcast_json({"shape": [5, 7], "who": "rank0"} if rank == 0 else None, root=0)
+            plane0 = (np.arange(35, dtype=np.float32).reshape(5, 7) * 0.5) if rank == 0 else None
+            plane = grp.broadcast_array(plane0, np.float32, meta["shape"], root=0)
+            assert meta == {"shape": [5, 7], "who": "rank0"}
+            if not corrupt:
+                assert np.array_equal(plane, np.arange(35, dtype=np.float32).reshape(5, 7) * 0.5)
             q.put((rank, "ok", n, tot))
         except RuntimeError as e:
             q.put((rank, "error", str(e), 0.0))
@@ -247,6 +256,10 @@ def _host_transport_worker(rank, world, xdir, mode, q):
     n = grp.broadcast_constants(root=0)
     mx = grp.allreduce([float(rank), 10.0 - rank], "max")
     mn = grp.allreduce([float(rank)], "min")
+    # arrays still reach every rank on the host transport (through the rendezvous directory)
+    arr = grp.broadcast_array(np.arange(6, dtype=np.uint16).reshape(2, 3) if rank == 0 else None, np.uint16, (2, 3))
+    assert np.array_equal(arr, np.arange(6, dtype=np.uint16).reshape(2, 3))
+    assert grp.broadcast_json([1, {"a": None}] if rank == 0 else "ignored") == [1, {"a": None}]
     grp.barrier()
     try:
         grp.broadcast_device(None, 16, 0)
@@ -394,9 +407,13 @@ def _zarr_rank_worker(rank, world, src_path, out_path, rdzv_dir, q):
 
     fl.destripe_planes = _oracle_destripe_planes  # no GPU here: the chunk-map logic is what is under test
     group = _RdzvBarrier(rank, world, rdzv_dir) if world > 1 else None
-    n, _ = zd.destripe_zarr(src_path, out_path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, None,
+    n, _ = zd.destripe_zarr_store(src_path, out_path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, None,
                             prediction_chunksize=(4, 48, 64), output_chunks=(1, 1, 4, 16, 16), rank=rank,
                             world_size=world, device=0, device_retile=False, group=group)  # fmt: skip
+    # codec threads: the cores of this process shared among the ranks of the node, at least 2
+    cores = len(os.sched_getaffinity(0))
+    assert zd.LAST_RUN["io_threads"] == max(2, min(cores // world, 64)), (zd.LAST_RUN, cores, world)
+    assert zd.LAST_RUN["rank"] == rank and zd.LAST_RUN["world_size"] == world
     q.put((rank, n))
 
 
@@ -444,7 +461,7 @@ def _zarr_rank_worker_nogroup(rank, world, src_path, out_path, delay, q):
 
     fl.destripe_planes = _oracle_destripe_planes
     time.sleep(delay)
-    n, _ = zd.destripe_zarr(src_path, out_path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, None,
+    n, _ = zd.destripe_zarr_store(src_path, out_path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, None,
                             prediction_chunksize=(4, 48, 64), output_chunks=(1, 1, 4, 16, 16), rank=rank,
                             world_size=world, device=0, device_retile=False, group=None, compressor="blosc")  # fmt: skip
     q.put((rank, n))
@@ -488,4 +505,91 @@ def test_destripe_channel_needs_group_for_many_ranks(tmp_path):
     from aind_smartspim_destripe_amd import zarr_destriper as zd
 
     with pytest.raises(ValueError):
-        zd.destripe_channel(str(tmp_path), str(tmp_path), "Ex_561_Em_593", str(tmp_path), {}, {}, {}, world_size=2)
+        zd.destripe_channel(str(tmp_path), str(tmp_path), "Ex_561_Em_593", str(tmp_path), None, {}, {}, {}, world_size=2)
+
+
+# ---- destripe_channel under two ranks: rank 0 alone reads the flat and dark planes, the group broadcasts them ----
+def _channel_rank_worker(rank, world, root, rdzv_dir, q):
+    sys.path.insert(0, REPO)
+    from aind_smartspim_destripe_amd import distributed as dd
+    from aind_smartspim_destripe_amd import filtering as fl
+    from aind_smartspim_destripe_amd import mini_tiff, synth, zarr_destriper as zd
+
+    fl.destripe_planes = _oracle_destripe_planes  # no GPU here: plumbing under test
+    reads = []
+    real_imread = mini_tiff.imread
+
+    def counting_imread(path, *a, **k):
+        reads.append(os.path.basename(str(path)))
+        if rank != 0 and world > 1:
+            raise AssertionError("rank {} opened {}: only rank 0 reads the shading planes".format(rank, path))
+        return real_imread(path, *a, **k)
+
+    mini_tiff.imread = counting_imread
+    group = None
+    if world > 1:
+        eng = _FakeEngine(rank, world, rdzv_dir)
+        orig_alloc = eng.alloc
+        eng.alloc = lambda n: orig_alloc(n)
+        group = dd.RankGroup(eng, rank, world, dd.FileRendezvous(rank, world, rdzv_dir))
+    params = {"cells_config": synth.CELLS_CONFIG, "no_cells_config": synth.NO_CELLS_CONFIG}
+    d = os.path.join(root, "derivatives")
+    done = zd.destripe_channel(
+        zarr_dataset_path=os.path.join(root, "data"), channel_name="Ex_488_Em_525",
+        results_folder=os.path.join(root, "results{}".format(world)), derivatives_path=d, xyz_resolution=[1.8, 1.8, 2.0],
+        estimated_channel_flats=[os.path.join(d, "flat_0.tif"), os.path.join(d, "flat_1.tif")],
+        laser_tiles={"0": ["431040_368180"], "1": ["431040_394100"]}, parameters=params,
+        prediction_chunksize=(4, 32, 48), output_chunks=(1, 1, 4, 16, 16), compressor="zlib", n_levels=1,
+        rank=rank, world_size=world, device=0, group=group, device_retile=False)  # fmt: skip
+    nbytes = group.bytes_broadcast if group is not None else 0
+    if group is not None:
+        group.close()
+    q.put((rank, done, sorted(set(reads)), nbytes))
+
+
+def test_two_rank_destripe_channel_broadcasts_the_shading_planes(tmp_path):
+    """``destripe_channel`` with the reference's keyword set under two ranks and a ``RankGroup``: rank 0 reads the flat
+    of each tile's laser side and ``DarkMaster_cropped.tif`` ONCE per tile and the group hands them to rank 1 (which
+    never opens a TIFF); both ranks correct with the same planes, and the store equals a one-rank run."""
+    import multiprocessing as mp
+
+    from aind_smartspim_destripe_amd import mini_tiff, synth
+    from aind_smartspim_destripe_amd.mini_zarr import MiniZarrArray
+
+    H, W, Z = 32, 48, 8
+    names = ["431040_368180", "431040_394100"]
+    for t, name in enumerate(names):
+        a = MiniZarrArray.create(str(tmp_path / "data" / "Ex_488_Em_525" / (name + ".zarr") / "0"), (1, 1, Z, H, W),
+                                 (1, 1, 4, 16, 16), np.uint16, compressor="zlib")  # fmt: skip
+        a[0, 0] = synth.synthetic_stack(Z, H, W, n_unique=4) + np.uint16(3 * t)
+    d = tmp_path / "derivatives"
+    d.mkdir()
+    mini_tiff.imwrite(str(d / "DarkMaster_cropped.tif"), np.full((H + 8, W + 8), 90, np.uint16))
+    yy, xx = np.mgrid[0:H, 0:W]
+    for side in (0, 1):
+        f = (1.0 + 0.2 * side - 0.3 * ((yy - H / 2) / H) ** 2 - 0.2 * ((xx - W / 2) / W) ** 2).astype(np.float32)
+        mini_tiff.imwrite(str(d / "flat_{}.tif".format(side)), f)
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_channel_rank_worker, args=(r, world, str(tmp_path), str(tmp_path / "rdzv"), q))
+                 for r in range(world)]  # fmt: skip
+        for p in procs:
+            p.start()
+        results[world] = sorted(q.get(timeout=300) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    tiles = [n + ".zarr" for n in names]
+    assert results[1][0][1] == {t: Z for t in tiles}
+    (r0, done0, reads0, sent0), (r1, done1, reads1, sent1) = results[2]
+    assert done0 == {t: 4 for t in tiles} and done1 == {t: 4 for t in tiles}  # two output z-chunks: one each
+    assert reads0 == ["DarkMaster_cropped.tif", "flat_0.tif", "flat_1.tif"] and reads1 == []
+    plane_bytes = H * W * 4 + (H + 8) * (W + 8) * 2
+    assert sent0 == sent1 == 2 * plane_bytes  # per tile: one flat (float32) + one dark (uint16), nothing else
+    for t in tiles:
+        a = MiniZarrArray.open(str(tmp_path / "results1" / "destriped_data" / "Ex_488_Em_525" / t / "0"))[0, 0]
+        b = MiniZarrArray.open(str(tmp_path / "results2" / "destriped_data" / "Ex_488_Em_525" / t / "0"))[0, 0]
+        np.testing.assert_array_equal(a, b)
+        assert a.std() > 0

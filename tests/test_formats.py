@@ -165,7 +165,7 @@ def test_gpu_compute_pyramid_and_multiscale(tmp_path):
     # store-to-store driver
     src = MiniZarrArray.create(str(tmp_path / "g" / "0"), v.shape, (1, 1, 64, 128, 128), np.uint16, compressor="zlib")
     src[...] = v
-    shapes = pyramid.compute_multiscale(str(tmp_path / "g" / "0"), str(tmp_path / "g"), n_levels=3, compressor="zlib")
+    shapes = pyramid.write_pyramid_levels(str(tmp_path / "g" / "0"), str(tmp_path / "g"), n_levels=3, compressor="zlib")
     assert shapes == [(1, 1, 35, 65, 100), (1, 1, 17, 32, 50)]
     for i in (1, 2):
         np.testing.assert_array_equal(MiniZarrArray.open(str(tmp_path / "g" / str(i)))[0, 0], want[i])
@@ -186,7 +186,7 @@ def test_destripe_zarr_device_retile_equals_host_path(tmp_path, in_chunks):
         path = str(tmp_path / "out_{}.zarr".format(int(mode)))
         total = 0
         for rank in range(2):
-            n, _ = zd.destripe_zarr(str(tmp_path / "X_0_Y_0.zarr"), path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG,
+            n, _ = zd.destripe_zarr_store(str(tmp_path / "X_0_Y_0.zarr"), path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG,
                                     prediction_chunksize=(8, 96, 128), output_chunks=(1, 1, 8, 32, 32), rank=rank,
                                     world_size=2, device=0, device_retile=mode)  # fmt: skip
             total += n

@@ -477,12 +477,14 @@ def test_gpu_destripe_channel_with_shading_and_pyramid(tmp_path):
         flats.append(f)
     params = {"cells_config": synth.CELLS_CONFIG, "no_cells_config": synth.NO_CELLS_CONFIG}
     with pytest.raises(ValueError):
-        zd.destripe_channel(tmp_path / "data", d, "Ex_488_Em_525", tmp_path / "results",
+        zd.destripe_channel(tmp_path / "data", d, "Ex_488_Em_525", tmp_path / "results", [1.8, 1.8, 2.0],
                             [d / "flat_0.tif", d / "flat_1.tif"], {"0": ["431040_368180"]}, params,
                             prediction_chunksize=(4, H, W))  # fmt: skip
-    done = zd.destripe_channel(tmp_path / "data", d, "Ex_488_Em_525", tmp_path / "results2",
-                               [d / "flat_0.tif", d / "flat_1.tif"],
-                               {"0": ["431040_368180"], "1": ["431040_394100"]}, params,
+    # the reference's caller, keyword for keyword (run_capsule.py:394-403), plus the engine's keyword-only extras
+    done = zd.destripe_channel(zarr_dataset_path=tmp_path / "data", channel_name="Ex_488_Em_525",
+                               results_folder=tmp_path / "results2", derivatives_path=d, xyz_resolution=[1.8, 1.8, 2.0],
+                               estimated_channel_flats=[d / "flat_0.tif", d / "flat_1.tif"],
+                               laser_tiles={"0": ["431040_368180"], "1": ["431040_394100"]}, parameters=params,
                                prediction_chunksize=(4, H, W), output_chunks=(1, 1, 4, 32, 32),
                                compressor="zlib")  # fmt: skip
     assert done == {"431040_368180.zarr": Z, "431040_394100.zarr": Z}

@@ -89,7 +89,7 @@ def test_iter_blocks_and_plane_guard(tmp_path):
     assert len(blocks) == 1 and blocks[0][0][0] == slice(64, 128)
     MiniZarrArray.create(str(tmp_path / "i.zarr"), (10, 40, 48), (4, 16, 16), np.uint16)
     with pytest.raises(ValueError):
-        zd.destripe_zarr(str(tmp_path / "i.zarr"), str(tmp_path / "o.zarr"), synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG,
+        zd.destripe_zarr_store(str(tmp_path / "i.zarr"), str(tmp_path / "o.zarr"), synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG,
                          prediction_chunksize=(4, 20, 48))  # fmt: skip
 
 
@@ -104,7 +104,7 @@ def test_destripe_zarr_end_to_end(tmp_path):
     src[0, 0] = stack
     total = 0
     for rank in range(2):
-        n, _ = zd.destripe_zarr(str(tmp_path / "X_0_Y_0.zarr"), str(tmp_path / "out.zarr"), synth.CELLS_CONFIG,
+        n, _ = zd.destripe_zarr_store(str(tmp_path / "X_0_Y_0.zarr"), str(tmp_path / "out.zarr"), synth.CELLS_CONFIG,
                                 synth.NO_CELLS_CONFIG, prediction_chunksize=(8, 96, 128),
                                 output_chunks=(1, 1, 8, 32, 32), rank=rank, world_size=2, device=0)  # fmt: skip
         total += n
@@ -146,7 +146,7 @@ def test_chunk_map_at_production_geometry_against_the_oracle(tmp_path):
     outs = {}
     for mode in (True, False):
         path = str(tmp_path / "out_{}.zarr".format(int(mode)))
-        n, _ = zd.destripe_zarr(str(tmp_path / name), path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, sc,
+        n, _ = zd.destripe_zarr_store(str(tmp_path / name), path, synth.CELLS_CONFIG, synth.NO_CELLS_CONFIG, sc,
                                 prediction_chunksize=(BZ, H, W), output_chunks=(1, 1, 64, 128, 128), device=0,
                                 device_retile=mode, compressor="blosc", io_threads=16)  # fmt: skip
         assert n == Z

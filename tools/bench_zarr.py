@@ -25,7 +25,7 @@ try:
     for name, kw in (("overlapped", {}),):
         for rep in range(2):  # second pass: plan + pinned buffers exist, page cache warm
             t0 = time.perf_counter()
-            planes, dt = zd.destripe_zarr(os.path.join(root, "in.zarr"), os.path.join(root, "out.zarr"), synth.CELLS_CONFIG,
+            planes, dt = zd.destripe_zarr_store(os.path.join(root, "in.zarr"), os.path.join(root, "out.zarr"), synth.CELLS_CONFIG,
                                           synth.NO_CELLS_CONFIG, None, prediction_chunksize=(64, H, W),
                                           output_chunks=(1, 1, 64, 128, 128), device=0, device_retile=True, io_threads=16, compressor=codec, **kw)
             res[name] = {"planes": planes, "seconds": round(time.perf_counter() - t0, 3)}
