@@ -447,7 +447,10 @@ DSX_HD void dsx_bfly_load(const dsx_c32* buf, int b, int nb, dsx_c32* v) {
 
 // butterfly + twiddles + autosort scatter of butterfly b (sub-transform stride s)
 // unit_tw: last pass of a transform (s * R == M, so p == 0 and every twiddle is 1)
-template <int R, int JK = (R - 1) / 2>
+// KO (odd-prime radices only): only the outputs X[0] and the pairs (X[k], X[R-k]), k <= KO, are computed and stored --
+// the LAST pass of a forward transform whose consumer reads a band |bin| <= kcut only (outputs q + s k: the pairs
+// beyond KO = (kcut + s - 1) / s lie outside the band); the other destinations keep what the pass before left there.
+template <int R, int JK = (R - 1) / 2, int KO = (R - 1) / 2>
 DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float inv_s, dsx_c32* v,
                            bool unit_tw = false) {
   const int q = (s == 1) ? 0 : dsx_mod_s(b, s, inv_s);
@@ -472,10 +475,11 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
 #endif
     for (int j = 1; j <= JK; ++j) dc = dsx_add(dc, v[j]);
     buf[dst] = dc;
+    static_assert(KO >= 1 && KO <= HP, "output pairs of an odd-prime butterfly");
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int k = 1; k <= HP; ++k) {
+    for (int k = 1; k <= KO; ++k) {
       dsx_c32 A = x0, B = dsx_mk(0.f, 0.f);
 #if defined(__HIPCC__)
 #pragma unroll

@@ -42,6 +42,11 @@
 #ifndef DSX_INV_MINW
 #define DSX_INV_MINW 1  // waves per SIMD the fused uint16 final kernel is compiled for
 #endif
+#ifndef DSX_FWD_PRUNE
+// level-1 row filter of 2048-wide planes: forward passes in the order 6, 9, 19 with the last (radix-19) pass pruned to the
+// output pairs inside the low-pass band (StaticFft<1>::run_forward); 0 = the order 19, 9, 6, every bin computed
+#define DSX_FWD_PRUNE 1
+#endif
 #ifndef DSX_FWD_MINW
 #define DSX_FWD_MINW 4  // waves per SIMD the fused uint16 forward kernel is compiled for (register cap 128)
 #endif
@@ -1318,7 +1323,7 @@ __device__ __forceinline__ float key_f32(unsigned k) {
   return as_f32((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-template <int R, int CPL, int JK = (R - 1) / 2>
+template <int R, int CPL, int JK = (R - 1) / 2, int KO = (R - 1) / 2>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int M, int s, float inv_s,
                                          int lane) {
   constexpr int MAXB = (CPL + R - 1) / R;
@@ -1335,7 +1340,7 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int M, i
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
     const int b = lane + kWave * i;
-    if (b < nb) dsx_bfly_store<R, JK>((dsx_c32*)buf, (const dsx_c32*)tw, b, s, inv_s, v[i], unit_tw);
+    if (b < nb) dsx_bfly_store<R, JK, KO>((dsx_c32*)buf, (const dsx_c32*)tw, b, s, inv_s, v[i], unit_tw);
     // keep the unrolled butterflies from being interleaved: their temporaries would all be live
     // at once (215+ VGPRs at 18 values per lane) for no gain -- other waves hide the latency
     __builtin_amdgcn_sched_barrier(0);
@@ -1422,6 +1427,30 @@ struct StaticFft<1> {  // level 1 of a 2048-wide plane
   static __device__ __forceinline__ void run(float2* buf, const float2* tw, int lane) {
     fft_static_passes<CPL, 1026, 1, 19, 9, 6>(buf, tw, lane);
   }
+#if DSX_FWD_PRUNE
+  // Forward transform whose consumer (the spectral step) only reads the bins k <= kcut and k >= M - kcut (the low-pass
+  // is an exact zero beyond, dsx_plan.h: kcut = 103 / 206 of 513 for the production configs): the passes run in the
+  // order 6, 9, 19, so that the LAST pass is the expensive radix-19 one -- outputs q + 54 k, q < 54 -- and only its
+  // pairs (k, 19 - k) with k <= (kcut + 53) / 54 are computed (2 / 4 of 9: 72 / 144 of its 324 multiply-adds); the
+  // bins it leaves stale are the ones the spectral step overwrites with zeros.  The mirror image of run_inverse.
+  template <int CPL, int KO>
+  static __device__ __forceinline__ void run_last_pruned(float2* buf, const float2* tw, int lane_in) {
+    fft_static_passes<CPL, 1026, 1, 6, 9>(buf, tw, lane_in);
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    fft_pass<19, CPL, 9, KO>(buf, tw, 1026, 54, 1.0f / 54.0f, lane);
+  }
+  template <int CPL>
+  static __device__ __forceinline__ void run_forward(float2* buf, const float2* tw, int lane, int kcut) {
+    const int ko = (kcut + 53) / 54;
+    if (ko <= 2) run_last_pruned<CPL, 2>(buf, tw, lane);
+    else if (ko <= 4) run_last_pruned<CPL, 4>(buf, tw, lane);
+    else run<CPL>(buf, tw, lane);
+  }
+#else
+  template <int CPL>
+  static __device__ __forceinline__ void run_forward(float2* buf, const float2* tw, int lane, int) { run<CPL>(buf, tw, lane); }
+#endif
   // Inverse transform of a spectrum that vanishes for kcut < k < M - kcut: the first pass (radix 19,
   // sources b + 54 j) only sees non-zero input pairs (j, 19 - j) for j <= (kcut + 53) / 54.
   template <int CPL, int JK>
@@ -1448,6 +1477,8 @@ struct StaticFft<2> {  // level 2 of a 2048-wide plane: 515 values embedded in 1
     fft_static_passes<CPL, 1071, 1, 17, 9, 7>(buf, tw, lane);
   }
   template <int CPL>
+  static __device__ __forceinline__ void run_forward(float2* buf, const float2* tw, int lane, int) { run<CPL>(buf, tw, lane); }
+  template <int CPL>
   static __device__ __forceinline__ void run_inverse(float2* buf, const float2* tw, int lane, int) {
     run<CPL>(buf, tw, lane);  // the embedded operator is not band-limited
   }
@@ -1461,6 +1492,10 @@ struct StaticFft<2> {  // level 2 of a 2048-wide plane: 515 values embedded in 1
     template <int CPL>                                                                             \
     static __device__ __forceinline__ void run(float2* buf, const float2* tw, int lane) {          \
       fft_static_passes<CPL, LEN, 1, R0, R1, R2>(buf, tw, lane);                                   \
+    }                                                                                              \
+    template <int CPL>                                                                             \
+    static __device__ __forceinline__ void run_forward(float2* buf, const float2* tw, int lane, int) { \
+      run<CPL>(buf, tw, lane);                                                                     \
     }                                                                                              \
     template <int CPL>                                                                             \
     static __device__ __forceinline__ void run_inverse(float2* buf, const float2* tw, int lane, int) { \
@@ -1818,7 +1853,7 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
   wave_sync();
 
   if (!DSX_ABL(a, 2)) {
-    if constexpr (PLAN_ > 0) StaticFft<PLAN_>::template run<CPL>(buf, s_tw, lane);
+    if constexpr (PLAN_ > 0) StaticFft<PLAN_>::template run_forward<CPL>(buf, s_tw, lane, a.kcut[cfg]);
     else fft_run<CPL>(buf, s_tw, a, lane);
   }
 

@@ -80,6 +80,63 @@ static void run_passes(std::vector<dsx_c32>& buf, const std::vector<dsx_c32>& tw
   }
 }
 
+static std::vector<dsx_c32> twiddles(int M);
+
+// The forward plan of the level-1 row filter at 2048 columns (StaticFft<1>::run_forward in csrc/dsx_kernels.h): passes
+// 6, 9 in full, then the radix-19 pass with only the output pairs k <= KO -- every bin |k| <= kcut must be the DFT.
+template <int KO>
+static double pruned_1026(int kcut) {
+  const int M = 1026;
+  std::vector<dsx_c32> buf(M), tw = twiddles(M);
+  std::vector<cd> x(M);
+  srand(1026 + KO);
+  for (int i = 0; i < M; ++i) {
+    x[i] = cd(rand() / (double)RAND_MAX - 0.5, rand() / (double)RAND_MAX - 0.5);
+    buf[i] = dsx_mk((float)x[i].real(), (float)x[i].imag());
+  }
+  const int first[2] = {6, 9};
+  // (run_passes derives the sub-transform stride from the radices it is given: 1, then 6)
+  {
+    int s = 1;
+    for (int pi = 0; pi < 2; ++pi) {
+      const int R = first[pi], nb = M / R;
+      const float inv_s = 1.0f / (float)s;
+      std::vector<dsx_c32> regs((size_t)nb * R);
+      for (int b = 0; b < nb; ++b) {
+        if (R == 6) dsx_bfly_load<6>(buf.data(), b, nb, &regs[(size_t)b * R]);
+        else dsx_bfly_load<9>(buf.data(), b, nb, &regs[(size_t)b * R]);
+      }
+      for (int b = 0; b < nb; ++b) {
+        if (R == 6) dsx_bfly_store<6>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R], false);
+        else dsx_bfly_store<9>(buf.data(), tw.data(), b, s, inv_s, &regs[(size_t)b * R], false);
+      }
+      s *= R;
+    }
+  }
+  {
+    const int R = 19, nb = M / R, s = 54;
+    std::vector<dsx_c32> regs((size_t)nb * R);
+    for (int b = 0; b < nb; ++b) dsx_bfly_load<19>(buf.data(), b, nb, &regs[(size_t)b * R]);
+    for (int b = 0; b < nb; ++b) dsx_bfly_store<19, 9, KO>(buf.data(), tw.data(), b, s, 1.0f / 54.0f, &regs[(size_t)b * R], true);
+  }
+  double err = 0, nrm = 0;
+  for (int k = 0; k < M; ++k) {
+    if (k > kcut && k < M - kcut) continue;
+    cd acc = 0;
+    for (int j = 0; j < M; ++j) acc += x[j] * std::polar(1.0, -2.0 * M_PI * (double)((long long)j * k % M) / M);
+    err = fmax(err, std::abs(acc - cd(buf[k].x, buf[k].y)));
+    nrm = fmax(nrm, std::abs(acc));
+  }
+  return err / nrm;
+}
+
+static int cmd_pruned() {
+  // kcut of the production configs at 2048 columns: 103 (cells) / 206 (no cells); 107 / 215 are the last bins 2 / 4 pairs reach
+  printf("{\"ko2_kcut103\": %.3e, \"ko2_kcut107\": %.3e, \"ko4_kcut206\": %.3e, \"ko4_kcut215\": %.3e, \"ko9_full\": %.3e}\n",
+         pruned_1026<2>(103), pruned_1026<2>(107), pruned_1026<4>(206), pruned_1026<4>(215), pruned_1026<9>(512));
+  return 0;
+}
+
 static std::vector<dsx_c32> twiddles(int M) {
   std::vector<dsx_c32> tw(M);
   for (int t = 0; t < M; ++t) {
@@ -206,6 +263,7 @@ int main(int argc, char** argv) {
   }
   if (argc >= 7 && !strcmp(argv[1], "rows"))
     return cmd_rows(atoi(argv[2]), atoi(argv[3]), atof(argv[4]), atoi(argv[5]), atoi(argv[6]));
-  fprintf(stderr, "usage: fft M | plan H W s0 l0 s1 l1 | rows H W sigma level lvl\n");
+  if (argc >= 2 && !strcmp(argv[1], "pruned")) return cmd_pruned();
+  fprintf(stderr, "usage: pruned | fft M | plan H W s0 l0 s1 l1 | rows H W sigma level lvl\n");
   return 2;
 }

@@ -57,6 +57,16 @@ def test_engine_fails_loudly_without_gpu(lib):
         filtering.log_space_fft_filtering(np.ones((16, 16), np.float32), level=1)
 
 
+def test_pruned_forward_plan_of_level_1(host_check):
+    """StaticFft<1>::run_forward (csrc/dsx_kernels.h): passes 6, 9 and a radix-19 last pass that only computes the output
+    pairs inside the low-pass band (``dsx_bfly_store<19, 9, KO>``).  Every bin the spectral step reads -- |k| <= kcut, for
+    the production kcut (103 / 206) and for the last bin 2 / 4 pairs reach (107 / 215) -- must be the DFT to float32
+    round-off, exactly as good as the unpruned pass (KO = 9)."""
+    r = host_check("pruned")
+    assert set(r) == {"ko2_kcut103", "ko2_kcut107", "ko4_kcut206", "ko4_kcut215", "ko9_full"}
+    assert all(v < 4e-7 for v in r.values()), r
+
+
 @pytest.mark.parametrize("m", [1, 2, 4, 12, 20, 36, 42, 63, 68, 117, 126, 132, 144, 260, 515, 567, 960, 1026, 1071, 229, 1080, 1280, 1815, 2048, 2304,
                                3003, 4693, 9252])  # (the last three: lengths of k_rowfilter_wide, 9252 = 6 * 6 * 257 with a generic pass)
 def test_fft_core_against_naive_dft(host_check, m):
