@@ -40,6 +40,16 @@ from aind_smartspim_destripe_amd import engine as eng_mod  # noqa: E402
 from aind_smartspim_destripe_amd import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
+# The attainable fraction of this algorithm in FP32 on gfx950 (derived from numbers in profiles/):
+# the chain at its floors -- 3.9 M vector wave-instructions and 50.2 MB of HBM traffic per 2048 x 2048 plane (32.4 read,
+# 17.8 written; level 1 materialised once: the decomposition that never materialises it trades 13 MB for + 1.4 M
+# instructions and is bound lower, by the vector units) -- needs 7.0 us of vector issue slots and, priced at the
+# measured 6.0 TB/s read and 3.5 TB/s write rates of this chip one after the other, 10.5 us of bus time per plane:
+# 95 k planes/s = 0.200 of the 8 TB/s data-sheet peak with both bounds perfectly overlapped.  (Reads and writes
+# overlap on the bus -- a copy moves 6.2 TB/s in all -- which would put the bound at 8.1 us = 0.259; no kernel pair
+# of this chain has been seen to reach that, so the additive figure is the one reported.)
+ATTAINABLE_FRAC_2048 = 0.200
+ATTAINABLE_FRAC_2048_RW_OVERLAPPED = 0.259
 SETTLE_SECONDS = 1.0  # untimed back-to-back steps before the warm-up: the chip reaches its steady clock
 
 
@@ -393,6 +403,7 @@ def main():
                         traffic_source = "profiles/{} was measured on another build (hash {}, library {}): not reported".format(
                             name, str(t.get("build_hash"))[:12], str(lib_hash)[:12])
                     break
+        attainable_applies = (H, W) == (2048, 2048) and args.wavelet == "db3" and not args.shading
         result = {
             "metric": "{}x{} uint16 slices/s destriped".format(H, W),
             "value": round(value, 2),
@@ -430,7 +441,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "destripe launch chain (k_fwd_march, k_hist, k_otsu, k_rowfilter, k_inv_march) over one batch",
+                "kernel": "destripe launch chain over one batch: k_fwd_march<u16, fused levels 1 + 2> -> coarse k_fwd_march x6 -> "
+                          "k_hist -> k_otsu -> k_rowfilter (levels 2 .. 8) -> k_inv_march x6 -> k_rowfinal (level-1 row filter + "
+                          "final synthesis: the dominant kernel, 53 % of a stream's time)",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -440,6 +453,13 @@ def main():
                 "algorithmic_bytes_per_launch": args.batch * algo_bytes_per_slice,
                 "device_ms_per_launch": round(dev_ms_per_step, 4),
                 "read_only_frac": round(achieved / 2 / HBM_PEAK_GBS, 5),
+                # what this algorithm can reach in FP32 on this chip (model: DESIGN.md section 4.4; 2048 x 2048, db3, no shading)
+                "attainable_frac": ATTAINABLE_FRAC_2048 if attainable_applies else None,
+                "frac_of_attainable": round(achieved / HBM_PEAK_GBS / ATTAINABLE_FRAC_2048, 4) if attainable_applies else None,
+                "attainable_frac_if_reads_and_writes_overlap": ATTAINABLE_FRAC_2048_RW_OVERLAPPED if attainable_applies else None,
+                "attainable_model": "DESIGN.md section 4.4: floors of the chain (3.9 M vector wave-instructions, 32.4 MB read + "
+                                    "17.8 MB written per plane) at 6.0 TB/s read, 3.5 TB/s write (measured), 4 clocks per "
+                                    "wave-instruction; the bus bound (10.5 us per plane) is the larger" if attainable_applies else None,
             },
         }
         if breakdown is not None:
