@@ -964,6 +964,20 @@ def test_device_buffer_path_reports_non_finite_planes_at_the_next_sync():
         with pytest.raises(ValueError, match="not finite"):  # the host-buffer call raises by itself ...
             e.run(bad, out_dtype=np.float32)
         e.sync()                                              # ... and leaves nothing behind
+        # a value error of an EARLIER asynchronous call that nobody has synchronised with yet must not be
+        # wiped by a host-buffer call that follows on the same context -- that call synchronises, so it reports it
+        d_in = e.alloc(bad.nbytes)
+        d_out = e.alloc(bad.nbytes)
+        try:
+            d_in.upload(bad)
+            e.run_device(d_in, np.float32, 3, d_out, np.float32)
+            with pytest.raises(ValueError, match="earlier dsx_run_device call"):
+                e.run(planes, out_dtype=np.float32)
+            np.testing.assert_array_equal(e.run(planes, out_dtype=np.float32), good)  # reported once; the engine works on
+            e.sync()
+        finally:
+            d_in.free()
+            d_out.free()
     finally:
         e.close()
 
