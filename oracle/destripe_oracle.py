@@ -210,12 +210,12 @@ def waverec2(coeffs, bank=DB3_BANK):
 # ----------------------------------------------------------------------------------------------
 # Otsu threshold (skimage 0.18.3 thresholding.py:282-350 on numpy.histogram)
 # ----------------------------------------------------------------------------------------------
-def histogram256(q, nbins=256):
+def histogram256(q, nbins=256, return_index=False):
     """``numpy.histogram(q.ravel(), bins=256)`` restated (numpy 1.26.4 histograms.py:800-850).
 
     Uniform edges ``linspace(min, max, 257, dtype=q.dtype)``; index estimate
     ``((q - min) / (max - min)) * 256`` corrected by +-1 against the edges; last bin closed.
-    Returns (counts int64[256], edges[257]).
+    Returns (counts int64[256], edges[257]); with ``return_index`` also the bin index of every element (raveled).
 
     The edges follow the reference's pinned NumPy 1.26.4 (``environment/Dockerfile:14-29``;
     ``core/function_base.py:128-177``): there ``linspace`` promotes its float32 end points to
@@ -241,6 +241,8 @@ def histogram256(q, nbins=256):
     inc = (a >= edges[idx + 1]) & (idx != nbins - 1)
     idx[inc] += 1
     counts = np.bincount(idx, minlength=nbins).astype(np.int64)
+    if return_index:
+        return counts, edges, idx
     return counts, edges
 
 

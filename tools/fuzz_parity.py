@@ -6,7 +6,8 @@ near-threshold mask decisions are forced into the oracle).  usage: python tools/
 kernels, on small planes down to a few pixels, the oracle running on the same filter bank;
 "geometry": every case ALSO draws the launch-geometry switches of the library -- DSX_SEG_MIN_ROWS, DSX_MARCH_WAVES,
 DSX_FWD_WPB / DSX_INV_WPB, DSX_ROW_WPB, DSX_HIST_ROWS, DSX_STREAMS, DSX_HELPER, DSX_NO_QUANT, DSX_NO_ROW_MULTI,
-DSX_ROW_MULTI_ALONE, DSX_NO_PAIR, DSX_NO_FUSE, DSX_NO_FUSE_INV, DSX_NO_FUSE_RF, DSX_NO_PIPELINE, DSX_GRAPH: each moves
+DSX_ROW_MULTI_ALONE, DSX_NO_PAIR, DSX_NO_FUSE, DSX_NO_FUSE_INV, DSX_NO_FUSE_RF, DSX_FUSE_RF_WIDE, DSX_NO_PIPELINE, DSX_GRAPH,
+DSX_PRIO: each moves
 segment boundaries, block heights or the launch chain, none may move a result -- on a fresh context per case (dsx_init
 reads them per context), with big multi-stream batches three times as often)
 Shapes favour the awkward ones: widths around multiples of 4 / 8 / 122 / 244 / 256 (strip and lane-pair boundaries of
@@ -39,14 +40,20 @@ GEOMETRY = {  # switch -> values a case draws from (None = unset: the library's 
     "DSX_NO_FUSE_RF": [None, None, 1],
     "DSX_NO_PIPELINE": [None, None, 1],
     "DSX_GRAPH": [None, None, None, 1],
+    "DSX_FUSE_RF_WIDE": [None, None, 1],           # k_rowfinal for the embedded plans of 2000- / 1800-wide planes (off by default)
+    "DSX_PRIO": [None, None, None, "0,-1,0,-1", "-1,0,1,0"],  # HIP stream priorities of the sub-cohort streams
 }
 
 
-def draw_geometry(rng):
-    """Sets / unsets the switches of GEOMETRY in os.environ; returns the drawn non-default ones."""
+def draw_geometry(rng, apply=True):
+    """Sets / unsets the switches of GEOMETRY in os.environ; returns the drawn non-default ones.  ``apply=False`` ("geometry-dry":
+    the same random stream, the library's defaults) tells a switch's doing from the plane's when a case fails."""
     drawn = {}
     for name, values in GEOMETRY.items():
         v = values[int(rng.integers(0, len(values)))]
+        if not apply:
+            os.environ.pop(name, None)
+            continue
         if v is None:
             os.environ.pop(name, None)
         else:
@@ -70,7 +77,7 @@ def run(cases=40, seed=2026, eng=None, any_wavelet=False, geometry=False):
             filtering.release_engines()
             if own and eng is not None:
                 eng.close()
-            drawn = draw_geometry(rng)
+            drawn = draw_geometry(rng, apply=geometry != "dry")
             eng = eng_mod.DestripeEngine(0)
             own = True
         anchor = int(rng.choice([64, 122, 128, 244, 256, 488, 512, 732, 976, 1220, 1708, 2048]))
@@ -78,8 +85,8 @@ def run(cases=40, seed=2026, eng=None, any_wavelet=False, geometry=False):
         if rng.random() < 0.6: w = (w + 3) & ~3          # fused kernels need a multiple of 4
         if rng.random() < 0.3: w = (w + 7) & ~7          # lane-pair I/O of the final kernel: multiple of 8
         h = int(rng.integers(40, 700))
-        if geometry and rng.random() < 0.15:             # the hot width: k_rowfinal and the compile-time FFT plans
-            w, h = 2048, int(rng.integers(64, 420)) & ~1
+        if geometry and rng.random() < 0.22:             # the hot widths: k_rowfinal and the compile-time FFT plans
+            w, h = int(rng.choice([2048, 2048, 2000, 1800])), int(rng.integers(64, 420)) & ~1
         if not any_wavelet and rng.random() < 0.03:      # rows longer than one wave holds (k_rowfilter_wide), few rows
             w = int(rng.choice([2304, 4606, 4608, 5120, 6001, 7000, 9216])) + int(rng.integers(0, 3))
             h = int(rng.integers(12, 90))
@@ -133,6 +140,15 @@ def run(cases=40, seed=2026, eng=None, any_wavelet=False, geometry=False):
                     err = e
                     n_regime_retries += 1
             if err is not None:
+                # keep the failing plane: the CPU side (oracle, histograms) can then be studied without a GPU
+                try:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_fail_%d_%d.npz" % (seed, c)), plane=src[k], out=out[k],
+                                        cfg=int(cfg[k]), cells=repr(cells), nocells=repr(nocells), high_int=high_int,
+                                        otsu=np.array(deltas[k].otsu, dtype=np.float64), drawn=repr(drawn),
+                                        **{"ch%d" % lv: np.asarray(a) for lv, a in enumerate(deltas[k].ch)})
+                except Exception as save_err:  # noqa: BLE001
+                    print("could not save the failing case:", save_err)
                 raise err
             n_planes += 1
         # now and then: the same planes many times over, split into cohorts and sub-cohort streams -- every copy of a
@@ -168,4 +184,5 @@ if __name__ == "__main__":
     import warnings
     warnings.simplefilter("ignore")  # "level too high" for long filters on small planes
     run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 2026,
-        any_wavelet=len(sys.argv) > 3 and sys.argv[3] == "wavelets", geometry=len(sys.argv) > 3 and sys.argv[3] == "geometry")
+        any_wavelet=len(sys.argv) > 3 and sys.argv[3] == "wavelets",
+        geometry=("dry" if sys.argv[3] == "geometry-dry" else True) if len(sys.argv) > 3 and sys.argv[3].startswith("geometry") else False)
