@@ -98,12 +98,21 @@ class FileRendezvous:
         of the same launch may already have keys in it)."""
         if self.rank != 0:
             return
+        now = time.time()
         for f in os.listdir(self.dir):
-            # this group's keys, and temporary files a put() that died left behind (nobody renames them any more)
-            if self.prefix and not (f.startswith(self.prefix) or f.startswith(".tmp_")):
+            path = os.path.join(self.dir, f)
+            if f.startswith(".tmp_"):
+                # a temporary file a put() that died left behind (nobody renames it any more) -- but a LATER group of this
+                # launch may be in the middle of a put right now: only files that have been lying around for a minute
+                try:
+                    if now - os.lstat(path).st_mtime < 60.0:
+                        continue
+                except OSError:
+                    continue
+            elif self.prefix and not f.startswith(self.prefix):
                 continue
             try:
-                os.remove(os.path.join(self.dir, f))
+                os.remove(path)
             except OSError:
                 pass
         try:
