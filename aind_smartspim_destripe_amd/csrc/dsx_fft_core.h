@@ -423,25 +423,40 @@ DSX_HD void dsx_bfly_composite(dsx_c32* v) {
   for (int k1 = 0; k1 < R1; ++k1) dsx_bfly<R2>::run(v + R2 * k1);
 }
 
+// ---- where element i of the row buffer / the twiddle table lives in LDS ---------------------------------------------
+// dsx_idx_plain: at i.  dsx_idx_swz (the power-of-two plans: 2 048 = 16 * 16 * 8, 1 024 = 16 * 8 * 8): the low four bits of
+// the index are XORed with bits 4 ... 7.  A Stockham pass of a power-of-two radix scatters its outputs at a power-of-two
+// stride -- the first pass of the 2 048-point plan at 16 complex values = 128 bytes: all 64 lanes of a store instruction
+// in the same two of the 32 LDS banks (rocprofv3: two thirds of that kernel's LDS cycles were bank conflicts, the LDS pipe
+// busy 55 % of the time).  With the swizzle consecutive sixteens of elements are permuted differently, so that sources
+// b + j M / R, destinations R b - (R - 1) q + s k and twiddles (b - q) k of 64 consecutive butterflies b all spread over
+// the banks evenly; no padding, the buffer keeps its size (lengths are multiples of 16).
+struct dsx_idx_plain {
+  DSX_HD static int at(int i) { return i; }
+};
+struct dsx_idx_swz {
+  DSX_HD static int at(int i) { return i ^ ((i >> 4) & 15); }
+};
+
 // ---- per-butterfly pieces of a pass (used verbatim by k_rowfilter and by the host unit test) ----
 // JK (odd-prime radices only): input pairs (x_j, x_{R-j}) with j > JK are known to be zero (band-limited
 // spectrum in the first pass of the inverse transform) and are neither loaded nor accumulated.
-template <int R, int JK = (R - 1) / 2>
+template <int R, int JK = (R - 1) / 2, class IX = dsx_idx_plain>
 DSX_HD void dsx_bfly_load(const dsx_c32* buf, int b, int nb, dsx_c32* v) {
   if constexpr (JK < (R - 1) / 2) {
-    v[0] = buf[b];
+    v[0] = buf[IX::at(b)];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int j = 1; j <= JK; ++j) {
-      v[j] = buf[b + DSX_IMUL(j, nb)];
-      v[R - j] = buf[b + DSX_IMUL(R - j, nb)];
+      v[j] = buf[IX::at(b + DSX_IMUL(j, nb))];
+      v[R - j] = buf[IX::at(b + DSX_IMUL(R - j, nb))];
     }
   } else {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int j = 0; j < R; ++j) v[j] = buf[b + DSX_IMUL(j, nb)];
+    for (int j = 0; j < R; ++j) v[j] = buf[IX::at(b + DSX_IMUL(j, nb))];
   }
 }
 
@@ -450,7 +465,7 @@ DSX_HD void dsx_bfly_load(const dsx_c32* buf, int b, int nb, dsx_c32* v) {
 // KO (odd-prime radices only): only the outputs X[0] and the pairs (X[k], X[R-k]), k <= KO, are computed and stored --
 // the LAST pass of a forward transform whose consumer reads a band |bin| <= kcut only (outputs q + s k: the pairs
 // beyond KO = (kcut + s - 1) / s lie outside the band); the other destinations keep what the pass before left there.
-template <int R, int JK = (R - 1) / 2, int KO = (R - 1) / 2>
+template <int R, int JK = (R - 1) / 2, int KO = (R - 1) / 2, class IX = dsx_idx_plain>
 DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float inv_s, dsx_c32* v,
                            bool unit_tw = false) {
   const int q = (s == 1) ? 0 : dsx_mod_s(b, s, inv_s);
@@ -474,7 +489,7 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
 #pragma unroll
 #endif
     for (int j = 1; j <= JK; ++j) dc = dsx_add(dc, v[j]);
-    buf[dst] = dc;
+    buf[IX::at(dst)] = dc;
     static_assert(KO >= 1 && KO <= HP, "output pairs of an odd-prime butterfly");
 #if defined(__HIPCC__)
 #pragma unroll
@@ -489,40 +504,40 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
         B = dsx_fma_s(v[R - j], dsx_root_sin(R, (j * k) % R), B);
       }
       if (unit_tw) {
-        buf[dst + DSX_IMUL(s, k)] = dsx_add(A, B);        // X[k]   = A - i B'   (B = -i B')
-        buf[dst + DSX_IMUL(s, R - k)] = dsx_sub(A, B);  // X[R-k] = A + i B'
+        buf[IX::at(dst + DSX_IMUL(s, k))] = dsx_add(A, B);        // X[k]   = A - i B'   (B = -i B')
+        buf[IX::at(dst + DSX_IMUL(s, R - k))] = dsx_sub(A, B);  // X[R-k] = A + i B'
       } else {
-        buf[dst + DSX_IMUL(s, k)] = dsx_mul(dsx_add(A, B), tw[DSX_IMUL(ps, k)]);
-        buf[dst + DSX_IMUL(s, R - k)] = dsx_mul(dsx_sub(A, B), tw[DSX_IMUL(ps, R - k)]);
+        buf[IX::at(dst + DSX_IMUL(s, k))] = dsx_mul(dsx_add(A, B), tw[IX::at(DSX_IMUL(ps, k))]);
+        buf[IX::at(dst + DSX_IMUL(s, R - k))] = dsx_mul(dsx_sub(A, B), tw[IX::at(DSX_IMUL(ps, R - k))]);
       }
     }
   } else if constexpr (dsx_comp<R>::R1 != 0) {
     dsx_bfly_composite<R>(v);
-    buf[dst] = v[0];
+    buf[IX::at(dst)] = v[0];
     if (unit_tw) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (int k = 1; k < R; ++k) buf[dst + DSX_IMUL(s, k)] = v[dsx_comp_pos<R>(k)];
+      for (int k = 1; k < R; ++k) buf[IX::at(dst + DSX_IMUL(s, k))] = v[dsx_comp_pos<R>(k)];
     } else {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (int k = 1; k < R; ++k) buf[dst + DSX_IMUL(s, k)] = dsx_mul(v[dsx_comp_pos<R>(k)], tw[DSX_IMUL(ps, k)]);
+      for (int k = 1; k < R; ++k) buf[IX::at(dst + DSX_IMUL(s, k))] = dsx_mul(v[dsx_comp_pos<R>(k)], tw[IX::at(DSX_IMUL(ps, k))]);
     }
   } else {
     dsx_bfly<R>::run(v);
-    buf[dst] = v[0];
+    buf[IX::at(dst)] = v[0];
     if (unit_tw) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (int k = 1; k < R; ++k) buf[dst + DSX_IMUL(s, k)] = v[k];
+      for (int k = 1; k < R; ++k) buf[IX::at(dst + DSX_IMUL(s, k))] = v[k];
     } else {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (int k = 1; k < R; ++k) buf[dst + DSX_IMUL(s, k)] = dsx_mul(v[k], tw[DSX_IMUL(ps, k)]);
+      for (int k = 1; k < R; ++k) buf[IX::at(dst + DSX_IMUL(s, k))] = dsx_mul(v[k], tw[IX::at(DSX_IMUL(ps, k))]);
     }
   }
 }

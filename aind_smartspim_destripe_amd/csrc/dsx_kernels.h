@@ -47,6 +47,11 @@
 // output pairs inside the low-pass band (StaticFft<1>::run_forward); 0 = the order 19, 9, 6, every bin computed
 #define DSX_FWD_PRUNE 1
 #endif
+#ifndef DSX_SWZ
+// bank-swizzled LDS addressing (dsx_fft_core.h: dsx_idx_swz) for the power-of-two row-filter plans 2 048 = 16 * 16 * 8 and
+// 1 024 = 16 * 8 * 8 (levels 1 and 2 of 2000-wide planes); 0 = plain addressing (A/B builds)
+#define DSX_SWZ 1
+#endif
 #ifndef DSX_FWD_MINW
 #define DSX_FWD_MINW 4  // waves per SIMD the fused uint16 forward kernel is compiled for (register cap 128)
 #endif
@@ -1323,7 +1328,7 @@ __device__ __forceinline__ float key_f32(unsigned k) {
   return as_f32((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-template <int R, int CPL, int JK = (R - 1) / 2, int KO = (R - 1) / 2>
+template <int R, int CPL, int JK = (R - 1) / 2, int KO = (R - 1) / 2, class IX = dsx_idx_plain>
 __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int M, int s, float inv_s,
                                          int lane) {
   constexpr int MAXB = (CPL + R - 1) / R;
@@ -1333,14 +1338,14 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* tw, int M, i
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
     const int b = lane + kWave * i;
-    if (b < nb) dsx_bfly_load<R, JK>((const dsx_c32*)buf, b, nb, v[i]);
+    if (b < nb) dsx_bfly_load<R, JK, IX>((const dsx_c32*)buf, b, nb, v[i]);
   }
   // LDS operations of one wave execute in program order: every read above precedes the writes below
   wave_sync();
 #pragma unroll
   for (int i = 0; i < MAXB; ++i) {
     const int b = lane + kWave * i;
-    if (b < nb) dsx_bfly_store<R, JK, KO>((dsx_c32*)buf, (const dsx_c32*)tw, b, s, inv_s, v[i], unit_tw);
+    if (b < nb) dsx_bfly_store<R, JK, KO, IX>((dsx_c32*)buf, (const dsx_c32*)tw, b, s, inv_s, v[i], unit_tw);
     // keep the unrolled butterflies from being interleaved: their temporaries would all be live
     // at once (215+ VGPRs at 18 values per lane) for no gain -- other waves hide the latency
     __builtin_amdgcn_sched_barrier(0);
@@ -1414,14 +1419,24 @@ __device__ __forceinline__ void fft_static_passes(float2* buf, const float2* tw,
   fft_pass<R, CPL>(buf, tw, M_, S_, 1.0f / (float)S_, lane);
   if constexpr (sizeof...(REST) > 0) fft_static_passes<CPL, M_, S_ * R, REST...>(buf, tw, lane_in);
 }
+// the same with the bank swizzle of dsx_idx_swz on the row buffer AND the twiddle table (power-of-two plans)
+template <int CPL, int M_, int S_, int R, int... REST>
+__device__ __forceinline__ void fft_static_passes_swz(float2* buf, const float2* tw, int lane_in) {
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
+  fft_pass<R, CPL, (R - 1) / 2, (R - 1) / 2, dsx_idx_swz>(buf, tw, M_, S_, 1.0f / (float)S_, lane);
+  if constexpr (sizeof...(REST) > 0) fft_static_passes_swz<CPL, M_, S_ * R, REST...>(buf, tw, lane_in);
+}
 // PLAN_ ids of k_rowfilter: 0 = passes from RowArgs; the others must match dsx.hip's dispatch.
 template <int PLAN_>
 struct StaticFft {
   static constexpr int M = 0;
+  static constexpr bool kSwz = false;  // dsx_idx_swz addressing of the row buffer and the twiddle table (rf_pair_body)
 };
 template <>
 struct StaticFft<1> {  // level 1 of a 2048-wide plane
   static constexpr int M = 1026;
+  static constexpr bool kSwz = false;
   static constexpr int kRadix[3] = {19, 9, 6};
   template <int CPL>
   static __device__ __forceinline__ void run(float2* buf, const float2* tw, int lane) {
@@ -1471,6 +1486,7 @@ struct StaticFft<1> {  // level 1 of a 2048-wide plane
 template <>
 struct StaticFft<2> {  // level 2 of a 2048-wide plane: 515 values embedded in 1071
   static constexpr int M = 1071;
+  static constexpr bool kSwz = false;
   static constexpr int kRadix[3] = {17, 9, 7};
   template <int CPL>
   static __device__ __forceinline__ void run(float2* buf, const float2* tw, int lane) {
@@ -1485,13 +1501,15 @@ struct StaticFft<2> {  // level 2 of a 2048-wide plane: 515 values embedded in 1
 };
 
 // Further compile-time plans: the wide levels of the production tile (1600 x 2000) and of 1800 x 1800 planes.
-#define DSX_STATIC_FFT(ID, LEN, R0, R1, R2)                                                        \
+#define DSX_STATIC_FFT(ID, LEN, R0, R1, R2, SWZ)                                                   \
   template <>                                                                                      \
   struct StaticFft<ID> {                                                                           \
     static constexpr int M = LEN;                                                                  \
+    static constexpr bool kSwz = SWZ;                                                              \
     template <int CPL>                                                                             \
     static __device__ __forceinline__ void run(float2* buf, const float2* tw, int lane) {          \
-      fft_static_passes<CPL, LEN, 1, R0, R1, R2>(buf, tw, lane);                                   \
+      if constexpr (SWZ) fft_static_passes_swz<CPL, LEN, 1, R0, R1, R2>(buf, tw, lane);            \
+      else fft_static_passes<CPL, LEN, 1, R0, R1, R2>(buf, tw, lane);                              \
     }                                                                                              \
     template <int CPL>                                                                             \
     static __device__ __forceinline__ void run_forward(float2* buf, const float2* tw, int lane, int) { \
@@ -1502,10 +1520,11 @@ struct StaticFft<2> {  // level 2 of a 2048-wide plane: 515 values embedded in 1
       run<CPL>(buf, tw, lane);                                                                     \
     }                                                                                              \
   };
-DSX_STATIC_FFT(3, 2048, 16, 16, 8)  // 1002 values (level 1 of a 2000-wide plane) embedded in 2048
-DSX_STATIC_FFT(4, 1815, 15, 11, 11) // 902 values (level 1 of an 1800-wide plane) embedded in 1815
-DSX_STATIC_FFT(5, 1024, 16, 8, 8)   // 503 values (level 2 of a 2000-wide plane) embedded in 1024
-DSX_STATIC_FFT(6, 960, 15, 8, 8)    // 453 values (level 2 of an 1800-wide plane) embedded in 960
+// (power-of-two lengths: their passes scatter at power-of-two strides -- bank-swizzled addressing, dsx_fft_core.h: dsx_idx_swz)
+DSX_STATIC_FFT(3, 2048, 16, 16, 8, DSX_SWZ != 0)  // 1002 values (level 1 of a 2000-wide plane) embedded in 2048
+DSX_STATIC_FFT(4, 1815, 15, 11, 11, false)         // 902 values (level 1 of an 1800-wide plane) embedded in 1815
+DSX_STATIC_FFT(5, 1024, 16, 8, 8, DSX_SWZ != 0)   // 503 values (level 2 of a 2000-wide plane) embedded in 1024
+DSX_STATIC_FFT(6, 960, 15, 8, 8, false)            // 453 values (level 2 of an 1800-wide plane) embedded in 960
 #undef DSX_STATIC_FFT
 
 typedef short dsx_s16x2 __attribute__((ext_vector_type(2)));
@@ -1606,6 +1625,9 @@ template <int CPL, int GF_, int NT_, int HALO_, int PLAN_, bool TO_LDS>
 __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, float2* buf, int tid, int nthreads, int lane,
                                              int pair, int plane) {
   const int M = (PLAN_ > 0) ? StaticFft<PLAN_>::M : a.M;
+  // P(i): where element i of the row buffer / twiddle table lives (bank swizzle of the power-of-two plans, else i)
+  constexpr bool SWZ = StaticFft<PLAN_>::kSwz;
+  auto P = [](int i) { return SWZ ? dsx_idx_swz::at(i) : i; };
   const int N = a.w, K = (HALO_ == 0) ? 0 : a.K;
   const bool halo = (HALO_ >= 0) ? (HALO_ != 0) : (K > 0);
   const int npairs = (a.h + 1) >> 1;
@@ -1662,7 +1684,7 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
       if (has_b) rtb[k] = rowb[tn + 64 * k];
     }
   }
-  for (int i = tid; i < M; i += nthreads) s_tw[i] = a.tw[i];
+  for (int i = tid; i < M; i += nthreads) s_tw[P(i)] = a.tw[i];
   __syncthreads();  // the only block-wide barrier: afterwards every wave works on its own rows
   float* const lds_a = (float*)buf;
   float* const lds_b = (float*)buf + rf_lds_row_b(M);
@@ -1840,15 +1862,15 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
       const float xa = bit_select(slot_mask(maska, e), meda, va[e]);
       const float xb = bit_select(slot_mask(maskb, e), medb, vb[e]);
       const float2 z = make_float2(xa, xb);
-      buf[K + n] = z;
+      buf[P(K + n)] = z;
       if (halo) {
-        if (n <= K) buf[K + N + n] = z;
-        if (n >= N - K) buf[n - (N - K)] = z;
+        if (n <= K) buf[P(K + N + n)] = z;
+        if (n >= N - K) buf[P(n - (N - K))] = z;
       }
     }
   });
   if (halo) {
-    for (int m = N + 2 * K + 1 + lane; m < M; m += kWave) buf[m] = make_float2(0.f, 0.f);
+    for (int m = N + 2 * K + 1 + lane; m < M; m += kWave) buf[P(m)] = make_float2(0.f, 0.f);
   }
   wave_sync();
 
@@ -1866,16 +1888,16 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
     const int kcut = a.kcut[cfg];
     for (int k = lane; k <= kcut; k += kWave) {
       const int kr = (k == 0) ? 0 : M - k;
-      const float2 u = buf[k], ur = buf[kr];
+      const float2 u = buf[P(k)], ur = buf[P(kr)];
       const float ga = g1[k].x;
       const float2 gb = g2[k];
       const float2 v = make_float2(ga * u.x + gb.x * ur.x - gb.y * ur.y, ga * u.y + gb.x * ur.y + gb.y * ur.x);
       const float2 vr = make_float2(ga * ur.x + gb.x * u.x + gb.y * u.y, ga * ur.y + gb.x * u.y - gb.y * u.x);
-      buf[k] = make_float2(v.y, v.x);
-      if (kr != k) buf[kr] = make_float2(vr.y, vr.x);
+      buf[P(k)] = make_float2(v.y, v.x);
+      if (kr != k) buf[P(kr)] = make_float2(vr.y, vr.x);
     }
     // beyond the band limit of the low-pass the product is an exact zero
-    for (int k = kcut + 1 + lane; k < M - kcut; k += kWave) buf[k] = make_float2(0.f, 0.f);
+    for (int k = kcut + 1 + lane; k < M - kcut; k += kWave) buf[P(k)] = make_float2(0.f, 0.f);
     wave_sync();
   }
 
@@ -1896,7 +1918,7 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
       oa[e] = 0.f;
       ob[e] = 0.f;
       if (e < 4 * GV || n < N) {
-        const float2 y = buf[K + n];
+        const float2 y = buf[P(K + n)];
         oa[e] = bit_select(slot_mask(maska, e), 0.f, -y.y * a.inv_M);
         ob[e] = bit_select(slot_mask(maskb, e) | no_b, 0.f, -y.x * a.inv_M);
       }
@@ -1930,7 +1952,7 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int e = 4 * g + i;
-        const float2 y = buf[K + nb0 + i];
+        const float2 y = buf[P(K + nb0 + i)];
         da_[i] = bit_select(slot_mask(maska, e), 0.f, -y.y * a.inv_M);
         db_[i] = bit_select(slot_mask(maskb, e), 0.f, -y.x * a.inv_M);
       }
@@ -1949,7 +1971,7 @@ __device__ __forceinline__ void rf_pair_body(const RowArgs& a, float2* s_tw, flo
     const int n = tn + 64 * k;
     if (k < nt && n < N) {
       const int e = 4 * GV + k;
-      const float2 y = buf[K + n];
+      const float2 y = buf[P(K + n)];
       rowa[n] = bit_select(slot_mask(maska, e), 0.f, -y.y * a.inv_M);
       if (has_b) rowb[n] = bit_select(slot_mask(maskb, e), 0.f, -y.x * a.inv_M);
     }

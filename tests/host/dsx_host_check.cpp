@@ -130,6 +130,45 @@ static double pruned_1026(int kcut) {
   return err / nrm;
 }
 
+// The power-of-two plans with bank-swizzled addressing (dsx_idx_swz on the row buffer AND the twiddle table, as
+// StaticFft<3> / <5> run them): the data is placed at sw(i), the twiddles at sw(t), every pass addresses through the
+// policy, and the result is read back from sw(k) -- it must be the DFT exactly as without the swizzle.
+template <int R>
+static void swz_pass(std::vector<dsx_c32>& buf, const std::vector<dsx_c32>& tw, int M, int s) {
+  const int nb = M / R;
+  std::vector<dsx_c32> regs((size_t)nb * R);
+  for (int b = 0; b < nb; ++b) dsx_bfly_load<R, (R - 1) / 2, dsx_idx_swz>(buf.data(), b, nb, &regs[(size_t)b * R]);
+  for (int b = 0; b < nb; ++b)
+    dsx_bfly_store<R, (R - 1) / 2, (R - 1) / 2, dsx_idx_swz>(buf.data(), tw.data(), b, s, 1.0f / (float)s, &regs[(size_t)b * R], s * R == M);
+}
+
+static double swizzled(int M) {
+  std::vector<dsx_c32> buf(M), plain = twiddles(M), tw(M);
+  std::vector<cd> x(M);
+  srand(M + 7);
+  for (int i = 0; i < M; ++i) {
+    x[i] = cd(rand() / (double)RAND_MAX - 0.5, rand() / (double)RAND_MAX - 0.5);
+    buf[dsx_idx_swz::at(i)] = dsx_mk((float)x[i].real(), (float)x[i].imag());
+    tw[dsx_idx_swz::at(i)] = plain[i];
+  }
+  if (M == 2048) { swz_pass<16>(buf, tw, M, 1); swz_pass<16>(buf, tw, M, 16); swz_pass<8>(buf, tw, M, 256); }
+  else { swz_pass<16>(buf, tw, M, 1); swz_pass<8>(buf, tw, M, 16); swz_pass<8>(buf, tw, M, 128); }
+  double err = 0, nrm = 0;
+  for (int k = 0; k < M; ++k) {
+    cd acc = 0;
+    for (int j = 0; j < M; ++j) acc += x[j] * std::polar(1.0, -2.0 * M_PI * (double)((long long)j * k % M) / M);
+    const dsx_c32 y = buf[dsx_idx_swz::at(k)];
+    err = fmax(err, std::abs(acc - cd(y.x, y.y)));
+    nrm = fmax(nrm, std::abs(acc));
+  }
+  return err / nrm;
+}
+
+static int cmd_swz() {
+  printf("{\"m2048\": %.3e, \"m1024\": %.3e}\n", swizzled(2048), swizzled(1024));
+  return 0;
+}
+
 static int cmd_pruned() {
   // kcut of the production configs at 2048 columns: 103 (cells) / 206 (no cells); 107 / 215 are the last bins 2 / 4 pairs reach
   printf("{\"ko2_kcut103\": %.3e, \"ko2_kcut107\": %.3e, \"ko4_kcut206\": %.3e, \"ko4_kcut215\": %.3e, \"ko9_full\": %.3e}\n",
@@ -264,6 +303,7 @@ int main(int argc, char** argv) {
   if (argc >= 7 && !strcmp(argv[1], "rows"))
     return cmd_rows(atoi(argv[2]), atoi(argv[3]), atof(argv[4]), atoi(argv[5]), atoi(argv[6]));
   if (argc >= 2 && !strcmp(argv[1], "pruned")) return cmd_pruned();
-  fprintf(stderr, "usage: pruned | fft M | plan H W s0 l0 s1 l1 | rows H W sigma level lvl\n");
+  if (argc >= 2 && !strcmp(argv[1], "swz")) return cmd_swz();
+  fprintf(stderr, "usage: pruned | swz | fft M | plan H W s0 l0 s1 l1 | rows H W sigma level lvl\n");
   return 2;
 }

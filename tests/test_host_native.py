@@ -57,6 +57,15 @@ def test_engine_fails_loudly_without_gpu(lib):
         filtering.log_space_fft_filtering(np.ones((16, 16), np.float32), level=1)
 
 
+def test_bank_swizzled_passes_of_the_power_of_two_plans(host_check):
+    """``dsx_idx_swz`` (csrc/dsx_fft_core.h): the 2 048- and 1 024-point plans address the row buffer and the twiddle table
+    with the low four index bits XORed with bits 4 ... 7 (their passes scatter at power-of-two strides: all lanes of a store
+    into two LDS banks otherwise).  Data placed at sw(i), twiddles at sw(t), passes run through the policy, result read
+    from sw(k): the DFT to float32 round-off, as without the swizzle."""
+    r = host_check("swz")
+    assert set(r) == {"m2048", "m1024"} and all(v < 4e-7 for v in r.values()), r
+
+
 def test_pruned_forward_plan_of_level_1(host_check):
     """StaticFft<1>::run_forward (csrc/dsx_kernels.h): passes 6, 9 and a radix-19 last pass that only computes the output
     pairs inside the low-pass band (``dsx_bfly_store<19, 9, KO>``).  Every bin the spectral step reads -- |k| <= kcut, for
