@@ -542,6 +542,83 @@ DSX_HD void dsx_bfly_store(dsx_c32* buf, const dsx_c32* tw, int b, int s, float 
   }
 }
 
+// ---- the passes of the power-of-two plans with the dsx_idx_swz addressing written out -------------------------------
+// sw(i) = i ^ ((i >> 4) & 15) only touches the low four index bits, and for the sources b + j M / R and destinations
+// R b - (R - 1) q + S k of ONE butterfly the XOR term takes one or two values: every access becomes "swizzled base +
+// compile-time offset" (an LDS instruction's immediate) instead of a shift, a mask and an XOR per access -- the generic
+// policy cost the 2 048-point row filter + 52 % vector instructions.  R is 16 or 8, M and S powers of two, M / R a
+// multiple of 128.  Same butterflies, same twiddle values and products as dsx_bfly_load / dsx_bfly_store with dsx_idx_swz.
+// bases of the accesses hi + j STEP (+ XOR term in the low four bits): the term (c + j STEP / 16) & 15 repeats with period
+// 256 / (largest power of two dividing STEP, at most 256)
+template <int STEP>
+struct dsx_swz_period {
+  static_assert(STEP % 16 == 0, "accesses of a butterfly must keep their low four index bits");
+  static constexpr int LOW = (STEP & -STEP) > 256 ? 256 : (STEP & -STEP);
+  static constexpr int P = 256 / LOW;  // 1 (STEP = 0 mod 256), 2 (128), 4 (64), ...
+};
+template <int R, int M>
+DSX_HD void dsx_swz_load(const dsx_c32* buf, int b, dsx_c32* v) {
+  constexpr int NB = M / R;
+  constexpr int P = dsx_swz_period<NB>::P;
+  const int r = b & 15, c = b >> 4, hi = b & ~15;
+  int base[P];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int m = 0; m < P; ++m) base[m] = hi | (r ^ ((c + m * (NB / 16)) & 15));
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int j = 0; j < R; ++j) v[j] = buf[base[j % P] + j * NB];
+}
+
+template <int R, int M, int S>
+DSX_HD void dsx_swz_store(dsx_c32* buf, const dsx_c32* tw, int b, dsx_c32* v) {
+  static_assert(dsx_comp<R>::R1 != 0 && (R == 16 || R == 8), "composite power-of-two radices only");
+  dsx_bfly_composite<R>(v);
+  if constexpr (S == 1) {
+    // first pass: q = 0, destinations R b + k, twiddles tw[b k]
+    static_assert(R == 16, "R b must be a multiple of 16");
+    const int r = b & 15, base = 16 * b;
+    buf[base + r] = v[0];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 1; k < R; ++k) {
+      const int t = DSX_IMUL(b, k);
+      buf[base + (k ^ r)] = dsx_mul(v[dsx_comp_pos<R>(k)], tw[t ^ ((t >> 4) & 15)]);
+    }
+  } else if constexpr (S * R == M) {
+    // last pass: q = b (b < S), destinations b + S k, unit twiddles
+    constexpr int P = dsx_swz_period<S>::P;
+    const int r = b & 15, c = b >> 4, hi = b & ~15;
+    int base[P];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int m = 0; m < P; ++m) base[m] = hi | (r ^ ((c + m * (S / 16)) & 15));
+    buf[base[0]] = v[0];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 1; k < R; ++k) buf[base[k % P] + k * S] = v[dsx_comp_pos<R>(k)];
+  } else {
+    // middle pass, S = 16: q = b & 15, p = b >> 4; destinations 16 R p + q + 16 k, twiddles tw[16 p k]
+    static_assert(S == 16, "middle pass of 16 * R * R'");
+    const int q = b & 15, p = b >> 4;
+    const int base = 16 * R * p;
+    const int x0 = DSX_IMUL(R, p) & 15;  // ((dst >> 4) & 15) = (R p + k) & 15: k for R = 16, k ^ (8 (p & 1)) for R = 8 (k < 8)
+    buf[base + (q ^ x0)] = v[0];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 1; k < R; ++k) {
+      const int m = DSX_IMUL(p, k);
+      buf[base + 16 * k + (q ^ ((x0 + k) & 15))] = dsx_mul(v[dsx_comp_pos<R>(k)], tw[16 * m + (m & 15)]);
+    }
+  }
+}
+
 // one output element o of a generic radix-R pass (any R dividing M / s)
 DSX_HD dsx_c32 dsx_generic_output(const dsx_c32* buf, const dsx_c32* tw, int o, int M, int s,
                                   float inv_s, int R) {

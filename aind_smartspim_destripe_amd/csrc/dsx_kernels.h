@@ -49,7 +49,8 @@
 #endif
 #ifndef DSX_SWZ
 // bank-swizzled LDS addressing (dsx_fft_core.h: dsx_idx_swz) for the power-of-two row-filter plans 2 048 = 16 * 16 * 8 and
-// 1 024 = 16 * 8 * 8 (levels 1 and 2 of 2000-wide planes); 0 = plain addressing (A/B builds)
+// 1 024 = 16 * 8 * 8 (levels 1 and 2 of 2000-wide planes); 0 = plain addressing, 2 = the swizzle through the generic index
+// policy instead of the written-out addressing (A/B builds)
 #define DSX_SWZ 1
 #endif
 #ifndef DSX_FWD_MINW
@@ -1419,12 +1420,36 @@ __device__ __forceinline__ void fft_static_passes(float2* buf, const float2* tw,
   fft_pass<R, CPL>(buf, tw, M_, S_, 1.0f / (float)S_, lane);
   if constexpr (sizeof...(REST) > 0) fft_static_passes<CPL, M_, S_ * R, REST...>(buf, tw, lane_in);
 }
-// the same with the bank swizzle of dsx_idx_swz on the row buffer AND the twiddle table (power-of-two plans)
+// the same with the bank swizzle of dsx_idx_swz on the row buffer AND the twiddle table (power-of-two plans), the
+// addressing written out as "swizzled base + immediate" (dsx_swz_load / dsx_swz_store)
+template <int R, int CPL, int M_, int S_>
+__device__ __forceinline__ void fft_pass_swz(float2* buf, const float2* tw, int lane) {
+  constexpr int MAXB = (CPL + R - 1) / R;
+  constexpr int NB = M_ / R;
+  dsx_c32 v[MAXB][R];
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int b = lane + kWave * i;
+    if (kWave * i + kWave <= NB || b < NB) dsx_swz_load<R, M_>((const dsx_c32*)buf, b, v[i]);
+  }
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int b = lane + kWave * i;
+    if (kWave * i + kWave <= NB || b < NB) dsx_swz_store<R, M_, S_>((dsx_c32*)buf, (const dsx_c32*)tw, b, v[i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wave_sync();
+}
 template <int CPL, int M_, int S_, int R, int... REST>
 __device__ __forceinline__ void fft_static_passes_swz(float2* buf, const float2* tw, int lane_in) {
   int lane = lane_in;
   asm volatile("" : "+v"(lane));
-  fft_pass<R, CPL, (R - 1) / 2, (R - 1) / 2, dsx_idx_swz>(buf, tw, M_, S_, 1.0f / (float)S_, lane);
+#if DSX_SWZ == 2
+  fft_pass<R, CPL, (R - 1) / 2, (R - 1) / 2, dsx_idx_swz>(buf, tw, M_, S_, 1.0f / (float)S_, lane);  // the generic policy (A/B)
+#else
+  fft_pass_swz<R, CPL, M_, S_>(buf, tw, lane);
+#endif
   if constexpr (sizeof...(REST) > 0) fft_static_passes_swz<CPL, M_, S_ * R, REST...>(buf, tw, lane_in);
 }
 // PLAN_ ids of k_rowfilter: 0 = passes from RowArgs; the others must match dsx.hip's dispatch.

@@ -142,6 +142,15 @@ static void swz_pass(std::vector<dsx_c32>& buf, const std::vector<dsx_c32>& tw, 
     dsx_bfly_store<R, (R - 1) / 2, (R - 1) / 2, dsx_idx_swz>(buf.data(), tw.data(), b, s, 1.0f / (float)s, &regs[(size_t)b * R], s * R == M);
 }
 
+// the same passes with the addressing written out (dsx_swz_load / dsx_swz_store): must give the very same bits
+template <int R, int M, int S>
+static void swz_pass_fast(std::vector<dsx_c32>& buf, const std::vector<dsx_c32>& tw) {
+  const int nb = M / R;
+  std::vector<dsx_c32> regs((size_t)nb * R);
+  for (int b = 0; b < nb; ++b) dsx_swz_load<R, M>(buf.data(), b, &regs[(size_t)b * R]);
+  for (int b = 0; b < nb; ++b) dsx_swz_store<R, M, S>(buf.data(), tw.data(), b, &regs[(size_t)b * R]);
+}
+
 static double swizzled(int M) {
   std::vector<dsx_c32> buf(M), plain = twiddles(M), tw(M);
   std::vector<cd> x(M);
@@ -151,8 +160,13 @@ static double swizzled(int M) {
     buf[dsx_idx_swz::at(i)] = dsx_mk((float)x[i].real(), (float)x[i].imag());
     tw[dsx_idx_swz::at(i)] = plain[i];
   }
+  std::vector<dsx_c32> fast = buf;
   if (M == 2048) { swz_pass<16>(buf, tw, M, 1); swz_pass<16>(buf, tw, M, 16); swz_pass<8>(buf, tw, M, 256); }
   else { swz_pass<16>(buf, tw, M, 1); swz_pass<8>(buf, tw, M, 16); swz_pass<8>(buf, tw, M, 128); }
+  if (M == 2048) { swz_pass_fast<16, 2048, 1>(fast, tw); swz_pass_fast<16, 2048, 16>(fast, tw); swz_pass_fast<8, 2048, 256>(fast, tw); }
+  else { swz_pass_fast<16, 1024, 1>(fast, tw); swz_pass_fast<8, 1024, 16>(fast, tw); swz_pass_fast<8, 1024, 128>(fast, tw); }
+  for (int i = 0; i < M; ++i)
+    if (memcmp(&fast[i], &buf[i], sizeof(dsx_c32)) != 0) return 1.0;  // written-out addressing differs from the policy
   double err = 0, nrm = 0;
   for (int k = 0; k < M; ++k) {
     cd acc = 0;
